@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE layer classes (build
+container only; needs /root/reference).  TEST INFRASTRUCTURE.
+
+Each fixture is data only: the layer's constructor arguments, its parameters,
+a seeded input ``u``, an upstream gradient ``gy``, and what the reference
+returned: ``y``, ``gu`` and one gradient per parameter.  Nothing of the
+reference's source is stored.
+
+    python tools/make_golden.py            # rewrite every fixture
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_loader  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def _run(layer, u, gy):
+    u = u.clone().requires_grad_(True)
+    y = layer(u)
+    names = [n for n, _ in layer.named_parameters()]
+    ps = [p for _, p in layer.named_parameters()]
+    grads = torch.autograd.grad(y, [u] + ps, gy, allow_unused=True)
+    out = {"y": y.detach(), "gu": grads[0]}
+    for n, g in zip(names, grads[1:]):
+        out["grad_" + n] = torch.zeros(()) if g is None else g
+        out["gradnone_" + n] = torch.tensor(g is None)
+    return out
+
+
+def _save(name, script, cls, ctor, layer, u, gy, dtype):
+    res = _run(layer, u, gy)
+    blob = {"u": u, "gy": gy}
+    for n, p in layer.named_parameters():
+        blob["param_" + n] = p.detach()
+    blob.update(res)
+    arrays = {k: v.detach().cpu().numpy() for k, v in blob.items()}
+    meta = {"script": script, "cls": cls, "ctor": ctor, "dtype": str(dtype).replace("torch.", "")}
+    arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name:40s} {os.path.getsize(path) / 1024:8.1f} KiB  |y|max={float(res['y'].abs().max()):.4g}")
+
+
+def _perturb(layer, g, rel=0.1, slope=0.0, dtype=torch.float32):
+    with torch.no_grad():
+        for n, p in layer.named_parameters():
+            if n in ("alpha_base", "beta_base"):
+                p.mul_(1 + rel * torch.randn(p.shape, generator=g, dtype=dtype))
+            elif n in ("alpha_time_coeff", "beta_time_coeff"):
+                p.copy_(slope * torch.randn(p.shape, generator=g, dtype=dtype))
+
+
+def make(name, script, cls, ctor, B, seed, dtype=torch.float32, tweak=None, u_fn=None):
+    mod = ref_loader.load(script)
+    g = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)  # constructors call torch.randn (cifar10.py:44, SVHN.py:26-27)
+    # fp64 fixtures: run the reference under a float64 default dtype, because its
+    # smoothing kernel is built with torch.ones(...) at the default dtype
+    # (mnist_test.py:144) and cannot follow layer.double().
+    torch.set_default_dtype(dtype)
+    try:
+        _make(name, script, cls, ctor, B, g, dtype, tweak, u_fn, mod)
+    finally:
+        torch.set_default_dtype(torch.float32)
+
+
+def _make(name, script, cls, ctor, B, g, dtype, tweak, u_fn, mod):
+    with ref_loader.quiet():
+        layer = getattr(mod, cls)(**ctor)
+    if tweak is not None:
+        tweak(layer, g)
+    if hasattr(layer, "channels"):
+        C = layer.channels
+    else:
+        C = 1
+    N = ctor.get("size", ctor.get("Nx", getattr(layer, "size", getattr(layer, "Nx", None))))
+    u = torch.randn(B, C, N, N, generator=g, dtype=dtype)
+    if u_fn is not None:
+        u = u_fn(u)
+    gy = torch.randn(B, C, N, N, generator=g, dtype=dtype)
+    _save(name, script, cls, ctor, layer, u, gy, dtype)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    f32, f64 = torch.float32, torch.float64
+
+    # ---- mnist_test.DiffusionLayer ------------------------------------------------
+    make("mnist_default", "mnist_test", "DiffusionLayer", {}, 3, 11)
+    make("mnist_default_f64", "mnist_test", "DiffusionLayer", {}, 2, 11, f64)
+    make("mnist_trained", "mnist_test", "DiffusionLayer", {}, 2, 12,
+         tweak=lambda L, g: _perturb(L, g, 0.1, 0.1))
+    make("mnist_dxdy_slopes", "mnist_test", "DiffusionLayer",
+         {"size": 12, "dt": 0.02, "dx": 0.5, "dy": 2.0, "num_steps": 3}, 3, 13,
+         tweak=lambda L, g: _perturb(L, g, 0.3, 20.0))
+
+    def clamp_const(L, g):
+        # some entries permanently below eps: clamp active at every sweep, mask constant in time
+        _perturb(L, g, 0.2, 0.0)
+        with torch.no_grad():
+            L.alpha_base[2:5, 3:9] = -0.5
+            L.beta_base[6:8, :] = -1.0
+    make("mnist_clamp_const", "mnist_test", "DiffusionLayer",
+         {"size": 12, "dt": 0.05, "num_steps": 2}, 2, 14, tweak=clamp_const)
+
+    def clamp_cross(L, g):
+        # base + slope*t crosses eps inside the time window: mask varies from sweep to sweep
+        _perturb(L, g, 0.2, 0.0)
+        with torch.no_grad():
+            L.alpha_base[1:6, 2:7] = 0.02
+            L.alpha_time_coeff[1:6, 2:7] = -0.5
+            L.beta_base[4:9, 0:5] = -0.03
+            L.beta_time_coeff[4:9, 0:5] = 0.6
+    make("mnist_clamp_cross", "mnist_test", "DiffusionLayer",
+         {"size": 12, "dt": 0.05, "num_steps": 3}, 2, 15, tweak=clamp_cross)
+    make("mnist_clamp_cross_f64", "mnist_test", "DiffusionLayer",
+         {"size": 12, "dt": 0.05, "num_steps": 3}, 2, 15, f64, tweak=clamp_cross)
+
+    # ---- fashion_mnist.DiffusionLayer ----------------------------------------------
+    make("fashion_default", "fashion_mnist", "DiffusionLayer", {}, 2, 21)
+    make("fashion_default_f64", "fashion_mnist", "DiffusionLayer", {}, 2, 21, f64)
+    make("fashion_trained", "fashion_mnist", "DiffusionLayer", {}, 2, 22,
+         tweak=lambda L, g: _perturb(L, g, 0.2, 0.5))
+
+    # ---- SVHN.DiffusionLayer -----------------------------------------------------------
+    make("svhn_default", "SVHN", "DiffusionLayer", {"size": 32, "channels": 3}, 2, 31)
+
+    def svhn_live(L, g):
+        _perturb(L, g, 0.2, 0.0)
+        with torch.no_grad():
+            C = L.channels
+            L.channel_coupling.copy_(torch.eye(C) + 0.05 * torch.randn(C, C, generator=g))
+            L.skip_weight.fill_(0.3)
+    make("svhn_live", "SVHN", "DiffusionLayer", {"size": 16, "channels": 3, "dt": 0.05, "num_steps": 4},
+         2, 32, tweak=svhn_live)
+    make("svhn_live_c5", "SVHN", "DiffusionLayer", {"size": 8, "channels": 5, "dt": 0.2, "num_steps": 2},
+         3, 33, tweak=svhn_live)
+
+    def svhn_identity(L, g):
+        _perturb(L, g, 0.2, 0.0)
+        with torch.no_grad():
+            L.channel_coupling.copy_(torch.eye(L.channels))
+            L.skip_weight.fill_(-40.0)
+    make("svhn_identity_c4", "SVHN", "DiffusionLayer", {"size": 28, "channels": 4, "dt": 0.3, "num_steps": 4},
+         2, 34, tweak=svhn_identity)
+
+    # ---- cifar10.EnhancedDiffusionLayer -------------------------------------------------
+    make("cifar10_default", "cifar10", "EnhancedDiffusionLayer", {"size": 32, "channels": 3}, 2, 41)
+    make("cifar10_default_f64", "cifar10", "EnhancedDiffusionLayer", {"size": 32, "channels": 3}, 2, 41, f64)
+    for i, (dt, steps, dx) in enumerate([(0.001, 5, 1.0), (0.002, 8, 2.0), (0.005, 4, 1.5)]):
+        make(f"cifar10_scale{i + 1}", "cifar10", "EnhancedDiffusionLayer",
+             {"size": 16, "channels": 3, "dt": dt, "num_steps": steps, "dx": dx, "dy": dx}, 2, 42 + i,
+             tweak=lambda L, g: _perturb(L, g, 0.1, 0.1))
+
+    def clampmax(L, g):
+        with torch.no_grad():
+            L.alpha_base.copy_(9.5 + 1.0 * torch.randn(L.alpha_base.shape, generator=g))
+            L.beta_base.copy_(9.8 + 0.5 * torch.randn(L.beta_base.shape, generator=g))
+    make("cifar10_clampmax", "cifar10", "EnhancedDiffusionLayer",
+         {"size": 12, "channels": 3, "dt": 0.02, "num_steps": 3}, 2, 46, tweak=clampmax)
+    make("cifar10_c8", "cifar10", "EnhancedDiffusionLayer",
+         {"size": 16, "channels": 8, "dt": 0.01, "num_steps": 3}, 2, 47,
+         tweak=lambda L, g: _perturb(L, g, 0.1, 1.0))
+
+    def mix_identity(L, g):
+        _perturb(L, g, 0.1, 0.1)
+        with torch.no_grad():
+            L.channel_mixing.copy_(torch.eye(L.channels))
+    make("cifar10_c16_mixI", "cifar10", "EnhancedDiffusionLayer",
+         {"size": 32, "channels": 16, "num_steps": 10}, 1, 48, tweak=mix_identity)
+
+    # ---- cifar_2version.LearnableDiffusionLayer -----------------------------------------
+    make("cifar2_default", "cifar_2version", "LearnableDiffusionLayer", {"size": 32, "channels": 3}, 2, 51)
+    make("cifar2_trained", "cifar_2version", "LearnableDiffusionLayer",
+         {"size": 16, "channels": 3, "dt": 0.05, "num_steps": 4}, 2, 52,
+         tweak=lambda L, g: _perturb(L, g, 0.2, 2.0))
+    make("cifar2_trained_f64", "cifar_2version", "LearnableDiffusionLayer",
+         {"size": 16, "channels": 3, "dt": 0.05, "num_steps": 4}, 2, 52, f64,
+         tweak=lambda L, g: _perturb(L, g, 0.2, 2.0, f64))
+
+    # ---- tiny_imagenet.ImprovedDiffusionLayer -------------------------------------------
+    make("tiny_default", "tiny_imagenet", "ImprovedDiffusionLayer", {"size": 64, "channels": 3}, 2, 61)
+
+    def tiny_tw(L, g):
+        with torch.no_grad():
+            C = L.channels
+            L.alpha_base.copy_(0.08 + 0.08 * torch.randn(C, generator=g))   # some above 0.15, some below 1e-6
+            L.channel_scaling.copy_(1 + 0.2 * torch.randn(C, generator=g))
+    make("tiny_trained_c6", "tiny_imagenet", "ImprovedDiffusionLayer", {"size": 16, "channels": 6}, 3, 62,
+         tweak=tiny_tw)
+    make("tiny_steps3", "tiny_imagenet", "ImprovedDiffusionLayer",
+         {"size": 20, "channels": 4, "dt": 0.5, "num_steps": 3}, 2, 63, tweak=tiny_tw)
+    make("tiny_steps3_f64", "tiny_imagenet", "ImprovedDiffusionLayer",
+         {"size": 20, "channels": 4, "dt": 0.5, "num_steps": 3}, 2, 63, f64,
+         tweak=lambda L, g: (tiny_tw(L, g)))
+
+    # ---- emotion_recognition.PDELayer ---------------------------------------------------
+    def emo_tame(L, g):
+        with torch.no_grad():
+            for n, v in dict(alpha_w1=0.05, alpha_w2=0.02, alpha_w3=-0.01,
+                             beta_w1=0.04, beta_w2=0.015, beta_w3=0.01).items():
+                getattr(L, n).fill_(v)
+    make("emotion_tame", "emotion_recognition", "PDELayer", {"Nx": 48, "Ny": 48}, 2, 71, tweak=emo_tame)
+    make("emotion_tame_f64", "emotion_recognition", "PDELayer", {"Nx": 48, "Ny": 48}, 2, 71, f64, tweak=emo_tame)
+    make("emotion_tame_24", "emotion_recognition", "PDELayer", {"Nx": 24, "Ny": 24, "T": 0.005}, 3, 72,
+         tweak=emo_tame)
+    # default parameters are beyond the explicit stability limit:
+    # keep the input smooth so the fixture stays finite and meaningful.
+    smooth = lambda u: torch.nn.functional.avg_pool2d(
+        torch.nn.functional.pad(u, (4, 4, 4, 4), mode="reflect"), 9, stride=1)
+    make("emotion_default_smooth", "emotion_recognition", "PDELayer", {}, 2, 73, u_fn=smooth)
+
+
+if __name__ == "__main__":
+    main()
