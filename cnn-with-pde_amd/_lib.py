@@ -1,0 +1,89 @@
+"""ctypes binding of libpdecnn_hip.so (C ABI in include/pdecnn.h).
+
+There is no CPU fallback and no routing through ``oracle/``: if the HIP library is
+missing or a call fails, this raises.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libpdecnn_hip.so")
+
+PDE_MAX_SWEEPS = 96
+PDE_MAX_N = 32
+PDE_IO_F32, PDE_IO_BF16 = 0, 1
+PDE_AXIS_X, PDE_AXIS_Y = 0, 1
+
+ERRORS = {
+    -1: "PDE_E_BADARG (null pointer, bad dimension or enum)",
+    -2: "PDE_E_UNSUPPORTED_N (line length must be a multiple of 4 in [8, 32])",
+    -3: "PDE_E_TOO_MANY_SWEEPS",
+    -4: "PDE_E_LAUNCH (HIP launch failed)",
+    -5: "PDE_E_WORKSPACE (workspace too small or misaligned)",
+}
+
+
+class PdeSweep(C.Structure):
+    _fields_ = [("axis", C.c_int32), ("delta", C.c_float), ("h2", C.c_float), ("t", C.c_float)]
+
+
+class PdeAdiDesc(C.Structure):
+    _fields_ = [("B", C.c_int32), ("C", C.c_int32), ("N", C.c_int32), ("io_dtype", C.c_int32),
+                ("num_sweeps", C.c_int32), ("smooth3", C.c_int32), ("has_clamp_max", C.c_int32),
+                ("clamp_max", C.c_float), ("eps", C.c_float), ("sweep", PdeSweep * PDE_MAX_SWEEPS)]
+
+
+class PdeError(RuntimeError):
+    pass
+
+
+_vp, _fp, _sz, _i32, _f32 = C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_float
+_D = C.POINTER(PdeAdiDesc)
+
+# name -> (restype, argtypes): must list every symbol include/pdecnn.h declares
+SIGNATURES = {
+    "pde_adi_forward_workspace_bytes": (_sz, [_D]),
+    "pde_adi_backward_workspace_bytes": (_sz, [_D, _i32]),
+    "pde_adi_forward": (C.c_int, [_D, _vp, _vp, _fp, _fp, _fp, _fp, _vp, _sz, _vp]),
+    "pde_adi_backward": (C.c_int, [_D, _vp, _vp, _vp, C.POINTER(C.c_uint64), _vp, _fp, _fp, _fp, _fp,
+                                   _fp, _fp, _fp, _fp, _vp, _sz, _vp]),
+    "pde_adi_kappa_max": (C.c_int, [_D, _fp, _fp, _fp, _fp, _fp, _vp]),
+    "pde_channel_mix_forward": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _fp, _vp, _vp]),
+    "pde_channel_mix_backward_workspace_bytes": (_sz, [_i32, _i32, _i32]),
+    "pde_channel_mix_backward": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _fp, _vp, _fp, _vp, _sz, _vp]),
+    "pde_explicit5_forward": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _fp, _fp, _f32, _f32, _f32, _f32, _vp, _vp]),
+    "pde_explicit5_backward_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
+    "pde_explicit5_backward": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _fp, _fp, _f32, _f32, _f32, _f32,
+                                         _vp, _fp, _fp, _vp, _sz, _vp]),
+    "pde_jacobi_forward": (C.c_int, [_i32, _i32, _i32, _i32, _fp, _fp, _fp, _fp, _vp]),
+    "pde_jacobi_backward_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
+    "pde_jacobi_backward": (C.c_int, [_i32, _i32, _i32, _i32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _sz, _vp]),
+    "pde_timing_enable": (C.c_int, [_i32]),
+    "pde_timing_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                                  C.POINTER(C.c_int64)]),
+    "pde_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library once; raise if it is not there (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise PdeError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C cnn-with-pde_amd/csrc`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)         # AttributeError if the library lacks a declared symbol
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise PdeError(f"{what} failed: {ERRORS.get(rc, rc)}")

@@ -1,0 +1,411 @@
+// K2 — explicit 5-point layers.
+//
+// explicit5: tiny_imagenet.py:34-72, one relaxed step
+//     a_c = clamp(alpha_base_c, eps, max_coeff);  v = s_c u
+//     out = u + relax*(v + a_c*dt*Lap0(v) - u)            Lap0: zero ghost cells (conv2d padding=1)
+//   HBM-bound: 4 B read + 4 B written per element; neighbours come from L1/L2.
+//   Backward (Lap0 is self-adjoint):
+//     gu   = (1-relax) g + relax*s_c*(g + a_c dt Lap0 g)
+//     gs_c = relax * sum (g + a_c dt Lap0 g) u
+//     ga_c = [eps <= alpha_base_c <= max_coeff] * relax*dt*s_c * sum (Lap0 g) u
+//   one workgroup per (b,c) plane writes its two partial sums; a second kernel adds
+//   them over b in a fixed order (no float atomics).
+//
+// jacobi: emotion_recognition.py:82-97, P = reflect_pad(u); nt times
+//     P_int += A_i (P[i+1,j]-2P[i,j]+P[i-1,j]) + B_j (P[i,j+1]-2P[i,j]+P[i,j-1]); ring frozen.
+//   One workgroup per sample, the padded plane lives in LDS for the whole time loop.
+//   Backward recomputes the forward, parking each state in the workspace, then walks the
+//   adjoint back, accumulating dA_i, dB_j per sample; a second kernel sums over samples.
+#include "pde_common.h"
+
+namespace pde {
+namespace {
+
+struct bf16e { unsigned short v; };
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned int)h << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) {
+    unsigned int u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+template <typename IO> struct V4;
+template <> struct V4<float> {
+    __device__ static __forceinline__ float4 ld(const float* p) { return *reinterpret_cast<const float4*>(p); }
+    __device__ static __forceinline__ void st(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+    __device__ static __forceinline__ float ld1(const float* p) { return *p; }
+};
+template <> struct V4<bf16e> {
+    __device__ static __forceinline__ float4 ld(const bf16e* p) {
+        const ushort4 q = *reinterpret_cast<const ushort4*>(p);
+        return make_float4(bf2f(q.x), bf2f(q.y), bf2f(q.z), bf2f(q.w));
+    }
+    __device__ static __forceinline__ void st(bf16e* p, float4 v) {
+        ushort4 q; q.x = f2bf(v.x); q.y = f2bf(v.y); q.z = f2bf(v.z); q.w = f2bf(v.w);
+        *reinterpret_cast<ushort4*>(p) = q;
+    }
+    __device__ static __forceinline__ float ld1(const bf16e* p) { return bf2f(p->v); }
+};
+
+// 5-point Laplacian with zero ghost cells of 4 consecutive columns (h, w0..w0+3) of one plane
+template <typename IO>
+__device__ __forceinline__ float4 lap0_4(const IO* plane, int H, int W, int h, int w0, const float4& c) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 n = (h > 0) ? V4<IO>::ld(plane + (size_t)(h - 1) * W + w0) : z;
+    const float4 s = (h + 1 < H) ? V4<IO>::ld(plane + (size_t)(h + 1) * W + w0) : z;
+    const float l = (w0 > 0) ? V4<IO>::ld1(plane + (size_t)h * W + w0 - 1) : 0.f;
+    const float r = (w0 + 4 < W) ? V4<IO>::ld1(plane + (size_t)h * W + w0 + 4) : 0.f;
+    float4 o;
+    o.x = n.x + s.x + l + c.y - 4.f * c.x;
+    o.y = n.y + s.y + c.x + c.z - 4.f * c.y;
+    o.z = n.z + s.z + c.y + c.w - 4.f * c.z;
+    o.w = n.w + s.w + c.z + r - 4.f * c.w;
+    return o;
+}
+
+template <typename IO>
+__global__ __launch_bounds__(256) void explicit5_fwd_kernel(const IO* __restrict__ u, const float* __restrict__ alpha,
+                                                            const float* __restrict__ scale, IO* __restrict__ out,
+                                                            int C, int H, int W, float dt, float eps, float maxc,
+                                                            float relax) {
+    const int pc = blockIdx.x;                         // plane index b*C + c
+    const int c = pc % C;
+    const float a = fminf(fmaxf(alpha[c], eps), maxc) * dt;
+    const float s = scale[c];
+    const IO* plane = u + (size_t)pc * H * W;
+    IO* oplane = out + (size_t)pc * H * W;
+    const int W4 = W / 4;
+    for (int f = threadIdx.x; f < H * W4; f += 256) {
+        const int h = f / W4, w0 = 4 * (f % W4);
+        const float4 cu = V4<IO>::ld(plane + (size_t)h * W + w0);
+        const float4 lp = lap0_4<IO>(plane, H, W, h, w0, cu);          // Lap0(u); Lap0(v) = s*Lap0(u)
+        float4 o;
+        // v = s u; new = v + a*(s*lap); out = u + relax*(new - u)
+        { const float v = s * cu.x; const float nw = v + a * (s * lp.x); o.x = cu.x + relax * (nw - cu.x); }
+        { const float v = s * cu.y; const float nw = v + a * (s * lp.y); o.y = cu.y + relax * (nw - cu.y); }
+        { const float v = s * cu.z; const float nw = v + a * (s * lp.z); o.z = cu.z + relax * (nw - cu.z); }
+        { const float v = s * cu.w; const float nw = v + a * (s * lp.w); o.w = cu.w + relax * (nw - cu.w); }
+        V4<IO>::st(oplane + (size_t)h * W + w0, o);
+    }
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+template <typename IO>
+__global__ __launch_bounds__(256) void explicit5_bwd_kernel(const IO* __restrict__ u, const IO* __restrict__ g,
+                                                            const float* __restrict__ alpha,
+                                                            const float* __restrict__ scale, IO* __restrict__ gu,
+                                                            float* __restrict__ part, int C, int H, int W, float dt,
+                                                            float eps, float maxc, float relax) {
+    __shared__ float sh[4];
+    const int pc = blockIdx.x;
+    const int c = pc % C;
+    const float a = fminf(fmaxf(alpha[c], eps), maxc) * dt;
+    const float s = scale[c];
+    const IO* up = u + (size_t)pc * H * W;
+    const IO* gp = g + (size_t)pc * H * W;
+    IO* op = gu + (size_t)pc * H * W;
+    const int W4 = W / 4;
+    float p1 = 0.f, p2 = 0.f;                          // sum g*u, sum Lap0(g)*u
+    for (int f = threadIdx.x; f < H * W4; f += 256) {
+        const int h = f / W4, w0 = 4 * (f % W4);
+        const float4 cg = V4<IO>::ld(gp + (size_t)h * W + w0);
+        const float4 cu = V4<IO>::ld(up + (size_t)h * W + w0);
+        const float4 lg = lap0_4<IO>(gp, H, W, h, w0, cg);
+        float4 o;
+        o.x = (1.f - relax) * cg.x + relax * s * (cg.x + a * lg.x);
+        o.y = (1.f - relax) * cg.y + relax * s * (cg.y + a * lg.y);
+        o.z = (1.f - relax) * cg.z + relax * s * (cg.z + a * lg.z);
+        o.w = (1.f - relax) * cg.w + relax * s * (cg.w + a * lg.w);
+        V4<IO>::st(op + (size_t)h * W + w0, o);
+        p1 += cg.x * cu.x + cg.y * cu.y + cg.z * cu.z + cg.w * cu.w;
+        p2 += lg.x * cu.x + lg.y * cu.y + lg.z * cu.z + lg.w * cu.w;
+    }
+    const float s1 = block_sum_256(p1, sh);
+    const float s2 = block_sum_256(p2, sh);
+    if (threadIdx.x == 0) { part[2 * (size_t)pc] = s1; part[2 * (size_t)pc + 1] = s2; }
+}
+
+__global__ void explicit5_pgrad_kernel(const float* __restrict__ part, const float* __restrict__ alpha,
+                                       const float* __restrict__ scale, float* __restrict__ ga,
+                                       float* __restrict__ gs, int B, int C, float dt, float eps, float maxc,
+                                       float relax) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int b = 0; b < B; ++b) { s1 += part[2 * ((size_t)b * C + c)]; s2 += part[2 * ((size_t)b * C + c) + 1]; }
+    const float ab = alpha[c];
+    const float a = fminf(fmaxf(ab, eps), maxc) * dt;
+    gs[c] = relax * (s1 + a * s2);
+    ga[c] = (ab >= eps && ab <= maxc) ? relax * dt * scale[c] * s2 : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------
+// jacobi (emotion_recognition.PDELayer)
+// ---------------------------------------------------------------------------------------
+constexpr int kJMax = 64;                  // max H, W
+constexpr int kJP = kJMax + 2;
+
+__device__ __forceinline__ int reflect_src(int m, int n) {   // padded index m in [0,n+1] -> source index in [0,n)
+    return m == 0 ? 1 : (m == n + 1 ? n - 2 : m - 1);
+}
+
+// one explicit update P -> Q of the interior; ring copied
+__device__ __forceinline__ void jacobi_step(const float* P, float* Q, const float* a, const float* b, int H, int W) {
+    const int Wp = W + 2;
+    for (int e = threadIdx.x; e < (H + 2) * Wp; e += blockDim.x) {
+        const int i = e / Wp, j = e % Wp;
+        float v = P[e];
+        if (i >= 1 && i <= H && j >= 1 && j <= W) {
+            const float d1 = P[e + Wp] - 2.f * v + P[e - Wp];
+            const float d2 = P[e + 1] - 2.f * v + P[e - 1];
+            v = v + a[i - 1] * d1 + b[j - 1] * d2;
+        }
+        Q[e] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void jacobi_fwd_kernel(const float* __restrict__ u, const float* __restrict__ a_row,
+                                                         const float* __restrict__ b_col, float* __restrict__ out,
+                                                         int H, int W, int nt) {
+    extern __shared__ float sm[];
+    const int Wp = W + 2, PN = (H + 2) * Wp;
+    float* P = sm;
+    float* Q = sm + PN;
+    float* a = sm + 2 * PN;
+    float* b = a + H;
+    const float* ub = u + (size_t)blockIdx.x * H * W;
+    for (int e = threadIdx.x; e < H; e += blockDim.x) a[e] = a_row[e];
+    for (int e = threadIdx.x; e < W; e += blockDim.x) b[e] = b_col[e];
+    for (int e = threadIdx.x; e < PN; e += blockDim.x) {
+        const int i = e / Wp, j = e % Wp;
+        P[e] = ub[reflect_src(i, H) * W + reflect_src(j, W)];          // F.pad(..., mode='reflect')
+    }
+    __syncthreads();
+    for (int n = 0; n < nt; ++n) {
+        jacobi_step(P, Q, a, b, H, W);
+        __syncthreads();
+        float* t = P; P = Q; Q = t;
+    }
+    float* ob = out + (size_t)blockIdx.x * H * W;
+    for (int e = threadIdx.x; e < H * W; e += blockDim.x) ob[e] = P[(e / W + 1) * Wp + (e % W) + 1];
+}
+
+// workspace per sample: nt states of PN floats, then H+W partial sums
+__global__ __launch_bounds__(256) void jacobi_bwd_kernel(const float* __restrict__ u, const float* __restrict__ gout,
+                                                         const float* __restrict__ a_row,
+                                                         const float* __restrict__ b_col, float* __restrict__ gu,
+                                                         float* __restrict__ states, float* __restrict__ part,
+                                                         int H, int W, int nt) {
+    extern __shared__ float sm[];
+    const int Wp = W + 2, PN = (H + 2) * Wp;
+    float* P = sm;
+    float* Q = sm + PN;
+    float* a = sm + 2 * PN;
+    float* b = a + H;
+    float* ga = b + W;
+    float* gb = ga + H;
+    const int s = blockIdx.x;
+    const float* ub = u + (size_t)s * H * W;
+    float* st = states + (size_t)s * nt * PN;
+    for (int e = threadIdx.x; e < H; e += blockDim.x) { a[e] = a_row[e]; ga[e] = 0.f; }
+    for (int e = threadIdx.x; e < W; e += blockDim.x) { b[e] = b_col[e]; gb[e] = 0.f; }
+    for (int e = threadIdx.x; e < PN; e += blockDim.x) {
+        const int i = e / Wp, j = e % Wp;
+        P[e] = ub[reflect_src(i, H) * W + reflect_src(j, W)];
+    }
+    __syncthreads();
+    // forward recompute: park the state BEFORE each step
+    for (int n = 0; n < nt; ++n) {
+        for (int e = threadIdx.x; e < PN; e += blockDim.x) st[(size_t)n * PN + e] = P[e];
+        jacobi_step(P, Q, a, b, H, W);
+        __syncthreads();
+        float* t = P; P = Q; Q = t;
+    }
+    // adjoint: G = dL/dP_nt (zero ring, gout inside)
+    float* G = P;
+    float* Gn = Q;
+    const float* gob = gout + (size_t)s * H * W;
+    for (int e = threadIdx.x; e < PN; e += blockDim.x) {
+        const int i = e / Wp, j = e % Wp;
+        G[e] = (i >= 1 && i <= H && j >= 1 && j <= W) ? gob[(i - 1) * W + (j - 1)] : 0.f;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int n = nt - 1; n >= 0; --n) {
+        const float* Pn = st + (size_t)n * PN;                 // state before step n (this block wrote it)
+        // coefficient gradients: dA_i += sum_j G[i,j] d1(Pn)[i,j];  dB_j += sum_i G[i,j] d2(Pn)[i,j]
+        for (int r = threadIdx.x; r < H + W; r += blockDim.x) {
+            float acc = 0.f;
+            if (r < H) {
+                const int i = r + 1;
+                for (int j = 1; j <= W; ++j) {
+                    const int e = i * Wp + j;
+                    acc += G[e] * (Pn[e + Wp] - 2.f * Pn[e] + Pn[e - Wp]);
+                }
+                ga[r] += acc;
+            } else {
+                const int j = r - H + 1;
+                for (int i = 1; i <= H; ++i) {
+                    const int e = i * Wp + j;
+                    acc += G[e] * (Pn[e + 1] - 2.f * Pn[e] + Pn[e - 1]);
+                }
+                gb[r - H] += acc;
+            }
+        }
+        // dL/dP_n from dL/dP_{n+1}
+        for (int e = threadIdx.x; e < PN; e += blockDim.x) {
+            const int i = e / Wp, j = e % Wp;
+            const bool in = (i >= 1 && i <= H && j >= 1 && j <= W);
+            float v = in ? (1.f - 2.f * a[i - 1] - 2.f * b[j - 1]) * G[e] : G[e];
+            if (j >= 1 && j <= W) {                                       // vertical neighbours are interior columns
+                if (i - 1 >= 1 && i - 1 <= H) v += a[i - 2] * G[e - Wp];
+                if (i + 1 >= 1 && i + 1 <= H) v += a[i] * G[e + Wp];
+            }
+            if (i >= 1 && i <= H) {
+                if (j - 1 >= 1 && j - 1 <= W) v += b[j - 2] * G[e - 1];
+                if (j + 1 >= 1 && j + 1 <= W) v += b[j] * G[e + 1];
+            }
+            Gn[e] = v;
+        }
+        __syncthreads();
+        float* t = G; G = Gn; Gn = t;
+    }
+    // adjoint of the reflect padding: fold the ring back onto rows/cols 1 and H-2 / W-2
+    float* gub = gu + (size_t)s * H * W;
+    for (int e = threadIdx.x; e < H * W; e += blockDim.x) {
+        const int i = e / W, j = e % W;
+        float v = 0.f;
+        for (int di = 0; di < 2; ++di) {
+            int m;
+            if (di == 0) m = i + 1;
+            else if (i == 1) m = 0;
+            else if (i == H - 2) m = H + 1;
+            else continue;
+            for (int dj = 0; dj < 2; ++dj) {
+                int nn;
+                if (dj == 0) nn = j + 1;
+                else if (j == 1) nn = 0;
+                else if (j == W - 2) nn = W + 1;
+                else continue;
+                v += G[m * Wp + nn];
+            }
+            // rows 1 and H-2 coincide when H == 3; not supported (H,W >= 4 checked on the host)
+        }
+        gub[e] = v;
+    }
+    float* pp = part + (size_t)s * (H + W);
+    for (int e = threadIdx.x; e < H; e += blockDim.x) pp[e] = ga[e];
+    for (int e = threadIdx.x; e < W; e += blockDim.x) pp[H + e] = gb[e];
+}
+
+__global__ void jacobi_pgrad_kernel(const float* __restrict__ part, float* __restrict__ ga, float* __restrict__ gb,
+                                    int B, int H, int W) {
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= H + W) return;
+    float s = 0.f;
+    for (int k = 0; k < B; ++k) s += part[(size_t)k * (H + W) + r];
+    if (r < H) ga[r] = s; else gb[r - H] = s;
+}
+
+size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+}  // namespace
+}  // namespace pde
+
+using namespace pde;
+
+extern "C" {
+
+int pde_explicit5_forward(int32_t B, int32_t C, int32_t H, int32_t W, int32_t io_dtype, const void* u,
+                          const float* alpha_base, const float* channel_scaling, float dt, float eps, float max_coeff,
+                          float relax, void* out, void* stream) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || (W % 4) != 0 || !u || !alpha_base || !channel_scaling || !out)
+        return PDE_E_BADARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (io_dtype == PDE_IO_F32)
+        hipLaunchKernelGGL((explicit5_fwd_kernel<float>), dim3(B * C), dim3(256), 0, st, (const float*)u, alpha_base,
+                           channel_scaling, (float*)out, C, H, W, dt, eps, max_coeff, relax);
+    else if (io_dtype == PDE_IO_BF16)
+        hipLaunchKernelGGL((explicit5_fwd_kernel<bf16e>), dim3(B * C), dim3(256), 0, st, (const bf16e*)u, alpha_base,
+                           channel_scaling, (bf16e*)out, C, H, W, dt, eps, max_coeff, relax);
+    else
+        return PDE_E_BADARG;
+    return check_launch();
+}
+
+size_t pde_explicit5_backward_workspace_bytes(int32_t B, int32_t C, int32_t H, int32_t W) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+    return align256((size_t)B * C * 2 * sizeof(float));
+}
+
+int pde_explicit5_backward(int32_t B, int32_t C, int32_t H, int32_t W, int32_t io_dtype, const void* u,
+                           const void* gout, const float* alpha_base, const float* channel_scaling, float dt,
+                           float eps, float max_coeff, float relax, void* gu, float* g_alpha_base,
+                           float* g_channel_scaling, void* workspace, size_t workspace_bytes, void* stream) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || (W % 4) != 0 || !u || !gout || !alpha_base || !channel_scaling ||
+        !gu || !g_alpha_base || !g_channel_scaling || !workspace)
+        return PDE_E_BADARG;
+    if (workspace_bytes < pde_explicit5_backward_workspace_bytes(B, C, H, W)) return PDE_E_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* part = static_cast<float*>(workspace);
+    if (io_dtype == PDE_IO_F32)
+        hipLaunchKernelGGL((explicit5_bwd_kernel<float>), dim3(B * C), dim3(256), 0, st, (const float*)u,
+                           (const float*)gout, alpha_base, channel_scaling, (float*)gu, part, C, H, W, dt, eps,
+                           max_coeff, relax);
+    else if (io_dtype == PDE_IO_BF16)
+        hipLaunchKernelGGL((explicit5_bwd_kernel<bf16e>), dim3(B * C), dim3(256), 0, st, (const bf16e*)u,
+                           (const bf16e*)gout, alpha_base, channel_scaling, (bf16e*)gu, part, C, H, W, dt, eps,
+                           max_coeff, relax);
+    else
+        return PDE_E_BADARG;
+    hipLaunchKernelGGL(explicit5_pgrad_kernel, dim3((C + 63) / 64), dim3(64), 0, st, part, alpha_base, channel_scaling,
+                       g_alpha_base, g_channel_scaling, B, C, dt, eps, max_coeff, relax);
+    return check_launch();
+}
+
+static size_t jacobi_lds(int H, int W, bool bwd) {
+    const size_t PN = (size_t)(H + 2) * (W + 2);
+    return (2 * PN + (bwd ? 2 : 1) * (H + W)) * sizeof(float);
+}
+
+int pde_jacobi_forward(int32_t B, int32_t H, int32_t W, int32_t nt, const float* u, const float* a_row,
+                       const float* b_col, float* out, void* stream) {
+    if (B <= 0 || H < 4 || W < 4 || H > kJMax || W > kJMax || nt < 0 || !u || !a_row || !b_col || !out)
+        return PDE_E_BADARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(jacobi_fwd_kernel, dim3(B), dim3(256), jacobi_lds(H, W, false), st, u, a_row, b_col, out, H, W, nt);
+    return check_launch();
+}
+
+size_t pde_jacobi_backward_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t nt) {
+    if (B <= 0 || H <= 0 || W <= 0 || nt < 0) return 0;
+    const size_t PN = (size_t)(H + 2) * (W + 2);
+    return align256((size_t)B * nt * PN * sizeof(float)) + align256((size_t)B * (H + W) * sizeof(float));
+}
+
+int pde_jacobi_backward(int32_t B, int32_t H, int32_t W, int32_t nt, const float* u, const float* gout,
+                        const float* a_row, const float* b_col, float* gu, float* g_a_row, float* g_b_col,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+    if (B <= 0 || H < 4 || W < 4 || H > kJMax || W > kJMax || nt < 0 || !u || !gout || !a_row || !b_col || !gu ||
+        !g_a_row || !g_b_col || !workspace)
+        return PDE_E_BADARG;
+    if (workspace_bytes < pde_jacobi_backward_workspace_bytes(B, H, W, nt)) return PDE_E_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t PN = (size_t)(H + 2) * (W + 2);
+    float* states = static_cast<float*>(workspace);
+    float* part = reinterpret_cast<float*>(static_cast<char*>(workspace) + align256((size_t)B * nt * PN * sizeof(float)));
+    hipLaunchKernelGGL(jacobi_bwd_kernel, dim3(B), dim3(256), jacobi_lds(H, W, true), st, u, gout, a_row, b_col, gu,
+                       states, part, H, W, nt);
+    hipLaunchKernelGGL(jacobi_pgrad_kernel, dim3((H + W + 63) / 64), dim3(64), 0, st, part, g_a_row, g_b_col, B, H, W);
+    return check_launch();
+}
+
+}  // extern "C"

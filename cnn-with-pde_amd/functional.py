@@ -1,0 +1,284 @@
+"""Differentiable operators of the PDE-layer hot path, backed by libpdecnn_hip.so.
+
+Each function is a ``torch.autograd.Function`` whose forward and backward enqueue the
+hand-written HIP kernels on the current stream.  PyTorch is used only for device
+memory, streams and autograd bookkeeping.  Nothing here has a CPU or eager fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+
+__all__ = ["Sweep", "adi_schedule", "adi_diffuse", "channel_mix", "explicit5_step", "jacobi_diffuse",
+           "timing_enable", "timing_read"]
+
+
+@dataclass(frozen=True)
+class Sweep:
+    """One implicit sweep: a diffuse_x / diffuse_y call of the reference (mnist_test.py:55-63)."""
+    axis: int        # 0: along W with alpha, 1: along H with beta
+    delta: float     # dt/2 or dt
+    h2: float        # dx**2 or dy**2
+    t: float         # current_time at which alpha/beta are evaluated
+
+
+def adi_schedule(dt: float, dx: float, dy: float, num_steps: int, split: str = "strang") -> List[List[Sweep]]:
+    """Sweeps of every time step, with ``current_time`` accumulated in Python double exactly
+    as the reference does (mnist_test.py:49-63 Strang; cifar_2version.py:79-101 Lie)."""
+    steps, t = [], 0.0
+    for _ in range(num_steps):
+        s = [Sweep(0, dt / 2, dx ** 2, t)]
+        t += dt / 2
+        if split == "strang":
+            s.append(Sweep(1, dt, dy ** 2, t))
+            t += dt / 2
+            s.append(Sweep(0, dt / 2, dx ** 2, t))
+        elif split == "lie":
+            s.append(Sweep(1, dt / 2, dy ** 2, t))
+            t += dt / 2
+        else:
+            raise ValueError(f"unknown split {split!r}")
+        steps.append(s)
+    return steps
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise L.PdeError("libpdecnn_hip operators need CUDA/HIP tensors (there is no CPU fallback)")
+
+
+def _io_dtype(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return L.PDE_IO_F32
+    if t.dtype == torch.bfloat16:
+        return L.PDE_IO_BF16
+    raise L.PdeError(f"unsupported tensor dtype {t.dtype} (float32 or bfloat16)")
+
+
+def _make_desc(B, Cc, N, io, sweeps: Sequence[Sweep], smooth3, clamp_max, eps) -> L.PdeAdiDesc:
+    if len(sweeps) > L.PDE_MAX_SWEEPS:
+        raise L.PdeError(f"{len(sweeps)} sweeps in one launch exceed PDE_MAX_SWEEPS={L.PDE_MAX_SWEEPS}")
+    d = L.PdeAdiDesc()
+    d.B, d.C, d.N, d.io_dtype, d.num_sweeps = B, Cc, N, io, len(sweeps)
+    d.smooth3 = int(bool(smooth3))
+    d.has_clamp_max = int(clamp_max is not None)
+    d.clamp_max = float(clamp_max) if clamp_max is not None else 0.0
+    d.eps = float(eps)
+    for i, s in enumerate(sweeps):
+        d.sweep[i].axis, d.sweep[i].delta, d.sweep[i].h2, d.sweep[i].t = int(s.axis), s.delta, s.h2, s.t
+    return d
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def _as_chw(p: torch.Tensor, Cc: int, N: int) -> torch.Tensor:
+    q = p.detach()
+    if q.dim() == 2:
+        q = q.unsqueeze(0)
+    if tuple(q.shape) != (Cc, N, N):
+        raise L.PdeError(f"coefficient of shape {tuple(p.shape)} does not match ({Cc},{N},{N})")
+    return q.to(torch.float32).contiguous()
+
+
+class _AdiFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, ab, bb, asl, bsl, sweeps, smooth3, clamp_max, eps):
+        lib = L.load()
+        _require_cuda(u, ab, bb, asl, bsl)
+        if u.dim() != 4 or u.shape[2] != u.shape[3]:
+            raise L.PdeError(f"expected (B,C,N,N), got {tuple(u.shape)}")
+        B, Cc, N, _ = u.shape
+        if u.dtype not in (torch.float32, torch.bfloat16):
+            u = u.float()
+        u = u.contiguous()
+        p = [_as_chw(t, Cc, N) for t in (ab, bb, asl, bsl)]
+        d = _make_desc(B, Cc, N, _io_dtype(u), sweeps, smooth3, clamp_max, eps)
+        y = torch.empty_like(u)
+        nbytes = lib.pde_adi_forward_workspace_bytes(C.byref(d))
+        ws = _workspace(nbytes, u.device)
+        with torch.cuda.device(u.device):
+            L.check(lib.pde_adi_forward(C.byref(d), _ptr(u), _ptr(y), *[_ptr(t) for t in p],
+                                        _ptr(ws), ws.numel(), _stream()), "pde_adi_forward")
+        ctx.save_for_backward(y, *p)
+        ctx.cfg = (sweeps, smooth3, clamp_max, eps)
+        ctx.param_shapes = [t.shape for t in (ab, bb, asl, bsl)]
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = L.load()
+        y, *p = ctx.saved_tensors
+        sweeps, smooth3, clamp_max, eps = ctx.cfg
+        B, Cc, N, _ = y.shape
+        gy = gy.to(y.dtype).contiguous()
+        d = _make_desc(B, Cc, N, _io_dtype(y), sweeps, smooth3, clamp_max, eps)
+        gu = torch.empty_like(y)
+        gp = [torch.empty_like(t) for t in p]
+        mask = (C.c_uint64 * 2)(0, 0)
+        nbytes = lib.pde_adi_backward_workspace_bytes(C.byref(d), 0)
+        ws = _workspace(nbytes, y.device)
+        with torch.cuda.device(y.device):          # autograd thread: set device, fetch the stream here
+            L.check(lib.pde_adi_backward(C.byref(d), _ptr(gy), _ptr(y), _ptr(None), mask, _ptr(gu),
+                                         *[_ptr(t) for t in p], *[_ptr(t) for t in gp],
+                                         _ptr(ws), ws.numel(), _stream()), "pde_adi_backward")
+        gp = [g.reshape(s) for g, s in zip(gp, ctx.param_shapes)]
+        return (gu, *gp, None, None, None, None)
+
+
+def adi_diffuse(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff, sweeps: Sequence[Sweep],
+                smooth3: bool = False, clamp_max: Optional[float] = None, eps: float = 1e-6):
+    """Run ``sweeps`` (a flat list) of implicit diffusion on ``u`` (B,C,N,N) in one fused launch.
+
+    Replaces the reference's time loop over diffuse_x/diffuse_y/thomas_solver_batch
+    (mnist_test.py:44-198, cifar10.py:74-211) and its autograd backward.
+    """
+    return _AdiFn.apply(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff, tuple(sweeps),
+                        bool(smooth3), clamp_max, float(eps))
+
+
+# --------------------------------------------------------------------------- channel mixing
+class _MixFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, M):
+        lib = L.load()
+        _require_cuda(u, M)
+        B, Cc = u.shape[0], u.shape[1]
+        HW = u[0, 0].numel()
+        if u.dtype not in (torch.float32, torch.bfloat16):
+            u = u.float()
+        u = u.contiguous()
+        Mf = M.detach().to(torch.float32).contiguous()
+        out = torch.empty_like(u)
+        with torch.cuda.device(u.device):
+            L.check(lib.pde_channel_mix_forward(B, Cc, HW, _io_dtype(u), _ptr(u), _ptr(Mf), _ptr(out), _stream()),
+                    "pde_channel_mix_forward")
+        ctx.save_for_backward(u, Mf)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = L.load()
+        u, Mf = ctx.saved_tensors
+        B, Cc = u.shape[0], u.shape[1]
+        HW = u[0, 0].numel()
+        gout = gout.to(u.dtype).contiguous()
+        gu = torch.empty_like(u)
+        gM = torch.empty_like(Mf)
+        ws = _workspace(lib.pde_channel_mix_backward_workspace_bytes(B, Cc, HW), u.device)
+        with torch.cuda.device(u.device):
+            L.check(lib.pde_channel_mix_backward(B, Cc, HW, _io_dtype(u), _ptr(u), _ptr(gout), _ptr(Mf), _ptr(gu),
+                                                 _ptr(gM), _ptr(ws), ws.numel(), _stream()),
+                    "pde_channel_mix_backward")
+        return gu, gM
+
+
+def channel_mix(u, M):
+    """out[b,i,p] = sum_j M[i,j] u[b,j,p] — cifar10.py:65-72 and SVHN.py:78-86."""
+    return _MixFn.apply(u, M)
+
+
+# --------------------------------------------------------------------------- explicit layers
+class _Explicit5Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, alpha_base, channel_scaling, dt, eps, max_coeff, relax):
+        lib = L.load()
+        _require_cuda(u, alpha_base, channel_scaling)
+        if u.dtype not in (torch.float32, torch.bfloat16):
+            u = u.float()
+        u = u.contiguous()
+        B, Cc, H, W = u.shape
+        a = alpha_base.detach().to(torch.float32).contiguous()
+        s = channel_scaling.detach().to(torch.float32).contiguous()
+        out = torch.empty_like(u)
+        with torch.cuda.device(u.device):
+            L.check(lib.pde_explicit5_forward(B, Cc, H, W, _io_dtype(u), _ptr(u), _ptr(a), _ptr(s), dt, eps, max_coeff,
+                                              relax, _ptr(out), _stream()), "pde_explicit5_forward")
+        ctx.save_for_backward(u, a, s)
+        ctx.cfg = (dt, eps, max_coeff, relax)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = L.load()
+        u, a, s = ctx.saved_tensors
+        dt, eps, max_coeff, relax = ctx.cfg
+        B, Cc, H, W = u.shape
+        gout = gout.to(u.dtype).contiguous()
+        gu = torch.empty_like(u)
+        ga, gs = torch.empty_like(a), torch.empty_like(s)
+        ws = _workspace(lib.pde_explicit5_backward_workspace_bytes(B, Cc, H, W), u.device)
+        with torch.cuda.device(u.device):
+            L.check(lib.pde_explicit5_backward(B, Cc, H, W, _io_dtype(u), _ptr(u), _ptr(gout), _ptr(a), _ptr(s), dt, eps,
+                                               max_coeff, relax, _ptr(gu), _ptr(ga), _ptr(gs), _ptr(ws), ws.numel(),
+                                               _stream()), "pde_explicit5_backward")
+        return gu, ga, gs, None, None, None, None
+
+
+def explicit5_step(u, alpha_base, channel_scaling, dt=0.01, eps=1e-6, max_coeff=0.15, relax=0.1):
+    """One relaxed explicit 5-point step — tiny_imagenet.py:38-49,53-72."""
+    return _Explicit5Fn.apply(u, alpha_base, channel_scaling, float(dt), float(eps), float(max_coeff), float(relax))
+
+
+class _JacobiFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, a_row, b_col, nt):
+        lib = L.load()
+        _require_cuda(u, a_row, b_col)
+        u = u.float().contiguous()
+        B, H, W = u.shape
+        a = a_row.detach().float().contiguous()
+        b = b_col.detach().float().contiguous()
+        out = torch.empty_like(u)
+        with torch.cuda.device(u.device):
+            L.check(lib.pde_jacobi_forward(B, H, W, nt, _ptr(u), _ptr(a), _ptr(b), _ptr(out), _stream()),
+                    "pde_jacobi_forward")
+        ctx.save_for_backward(u, a, b)
+        ctx.nt = nt
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = L.load()
+        u, a, b = ctx.saved_tensors
+        B, H, W = u.shape
+        gout = gout.float().contiguous()
+        gu, ga, gb = torch.empty_like(u), torch.empty_like(a), torch.empty_like(b)
+        ws = _workspace(lib.pde_jacobi_backward_workspace_bytes(B, H, W, ctx.nt), u.device)
+        with torch.cuda.device(u.device):
+            L.check(lib.pde_jacobi_backward(B, H, W, ctx.nt, _ptr(u), _ptr(gout), _ptr(a), _ptr(b), _ptr(gu), _ptr(ga),
+                                            _ptr(gb), _ptr(ws), ws.numel(), _stream()), "pde_jacobi_backward")
+        return gu, ga, gb, None
+
+
+def jacobi_diffuse(u, a_row, b_col, nt: int):
+    """emotion_recognition.py:82-97 on (B,H,W): reflect-pad once, ``nt`` Jacobi updates."""
+    return _JacobiFn.apply(u, a_row, b_col, int(nt))
+
+
+# --------------------------------------------------------------------------- timing
+def timing_enable(on: bool = True):
+    L.check(L.load().pde_timing_enable(int(on)), "pde_timing_enable")
+
+
+def timing_read() -> Tuple[float, int, float, int]:
+    """(sum of forward-kernel ms, launches, sum of backward-kernel ms, launches) since enable."""
+    f, b = C.c_double(), C.c_double()
+    nf, nb = C.c_int64(), C.c_int64()
+    L.check(L.load().pde_timing_read(C.byref(f), C.byref(nf), C.byref(b), C.byref(nb)), "pde_timing_read")
+    return f.value, nf.value, b.value, nb.value

@@ -1,0 +1,234 @@
+"""nn.Module surface of the reference's PDE layers, running on libpdecnn_hip.so.
+
+Every class keeps the reference's constructor signature (positional order), parameter
+names / shapes / initial values (they are state_dict keys, optimizer-group selectors and
+regulariser selectors — SURVEY.md §8b), plain attributes and helper methods, so a reference
+``state_dict`` loads unchanged and the reference's training / plotting code can keep reaching
+into ``model.diff.alpha_base`` etc.  ``forward`` returns a new tensor and never mutates its
+input.  There is no CPU path: calling a layer on CPU tensors raises.
+
+    reference class                               here
+    mnist_test.DiffusionLayer                     MnistDiffusionLayer
+    fashion_mnist.DiffusionLayer                  FashionDiffusionLayer
+    SVHN.DiffusionLayer                           SvhnDiffusionLayer
+    cifar10.EnhancedDiffusionLayer                EnhancedDiffusionLayer
+    cifar_2version.LearnableDiffusionLayer        LearnableDiffusionLayer
+    tiny_imagenet.ImprovedDiffusionLayer          ImprovedDiffusionLayer
+    emotion_recognition.PDELayer                  PDELayer
+
+``compat/<script>.py`` re-exports each one under the reference's own class name.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import functional as F_
+
+__all__ = ["MnistDiffusionLayer", "FashionDiffusionLayer", "SvhnDiffusionLayer", "EnhancedDiffusionLayer",
+           "LearnableDiffusionLayer", "ImprovedDiffusionLayer", "PDELayer"]
+
+
+class _AdiBase(nn.Module):
+    """Shared machinery of the implicit (Thomas) layers."""
+    _split = "strang"
+    _smooth3 = False
+    _clamp_max = None
+
+    def _schedule(self):
+        dy = getattr(self, "dy", self.dx)
+        return F_.adi_schedule(self.dt, self.dx, dy, self.num_steps, self._split)
+
+    def get_alpha_beta_at_time(self, t):
+        """clamp(base + slope*t) — mnist_test.py:33-42 / cifar10.py:53-63 (host-side helper)."""
+        alpha_t = self.alpha_base + self.alpha_time_coeff * t
+        beta_t = self.beta_base + self.beta_time_coeff * t
+        if self._clamp_max is None:
+            return torch.clamp(alpha_t, min=self.stability_eps), torch.clamp(beta_t, min=self.stability_eps)
+        return (torch.clamp(alpha_t, min=self.stability_eps, max=self._clamp_max),
+                torch.clamp(beta_t, min=self.stability_eps, max=self._clamp_max))
+
+    def _diffuse(self, u, sweeps):
+        return F_.adi_diffuse(u, self.alpha_base, self.beta_base, self.alpha_time_coeff, self.beta_time_coeff,
+                              sweeps, smooth3=self._smooth3, clamp_max=self._clamp_max, eps=self.stability_eps)
+
+
+class MnistDiffusionLayer(_AdiBase):
+    """mnist_test.py:11-219.  (B,1,size,size) -> same; Strang split, smoothed coefficients."""
+    _smooth3 = True
+
+    def __init__(self, size=28, dt=0.001, dx=1.0, dy=1.0, num_steps=10):
+        super().__init__()
+        self.size, self.dt, self.dx, self.dy, self.num_steps = size, dt, dx, dy, num_steps
+        self.alpha_base = nn.Parameter(torch.ones(size, size) * 2.0)
+        self.beta_base = nn.Parameter(torch.ones(size, size) * 2.0)
+        self.alpha_time_coeff = nn.Parameter(torch.zeros(size, size))
+        self.beta_time_coeff = nn.Parameter(torch.zeros(size, size))
+        self.stability_eps = 1e-6
+        print(f"Initialized DiffusionLayer with dx={dx}, dy={dy}")
+
+    def forward(self, u):
+        if u.dim() != 4 or u.shape[1] != 1:
+            raise ValueError(f"expected (B,1,{self.size},{self.size}), got {tuple(u.shape)}")
+        return self._diffuse(u, [s for step in self._schedule() for s in step])
+
+    def get_numerical_stability_info(self):
+        """mnist_test.py:200-219."""
+        with torch.no_grad():
+            alpha_max = torch.max(self.alpha_base + torch.abs(self.alpha_time_coeff) * self.dt * self.num_steps)
+            beta_max = torch.max(self.beta_base + torch.abs(self.beta_time_coeff) * self.dt * self.num_steps)
+            cfl_x = alpha_max * self.dt / (self.dx ** 2)
+            cfl_y = beta_max * self.dt / (self.dy ** 2)
+            return {"cfl_x": cfl_x.item(), "cfl_y": cfl_y.item(), "dx": self.dx, "dy": self.dy, "dt": self.dt,
+                    "stable_x": cfl_x.item() < 0.5, "stable_y": cfl_y.item() < 0.5}
+
+
+class FashionDiffusionLayer(_AdiBase):
+    """fashion_mnist.py:18-196: the mnist layer with dy == dx, dt=0.3, 4 steps, base 1.8."""
+    _smooth3 = True
+
+    def __init__(self, size=28, dt=0.3, dx=1.0, num_steps=4):
+        super().__init__()
+        self.size, self.dt, self.dx, self.num_steps = size, dt, dx, num_steps
+        self.alpha_base = nn.Parameter(torch.ones(size, size) * 1.8)
+        self.beta_base = nn.Parameter(torch.ones(size, size) * 1.8)
+        self.alpha_time_coeff = nn.Parameter(torch.zeros(size, size))
+        self.beta_time_coeff = nn.Parameter(torch.zeros(size, size))
+        self.stability_eps = 1e-6
+
+    def forward(self, u):
+        if u.dim() != 4 or u.shape[1] != 1:
+            raise ValueError(f"expected (B,1,{self.size},{self.size}), got {tuple(u.shape)}")
+        return self._diffuse(u, [s for step in self._schedule() for s in step])
+
+
+class SvhnDiffusionLayer(_AdiBase):
+    """SVHN.py:12-230: per-channel smoothed Strang steps, channel coupling after every step
+    (SVHN.py:71), learnable sigmoid skip blend with the input (SVHN.py:74)."""
+    _smooth3 = True
+
+    def __init__(self, size=32, channels=3, dt=0.01, dx=1.0, num_steps=10):
+        super().__init__()
+        self.size, self.channels, self.dt, self.dx, self.num_steps = size, channels, dt, dx, num_steps
+        self.alpha_base = nn.Parameter(torch.ones(channels, size, size) * 0.1)
+        self.beta_base = nn.Parameter(torch.ones(channels, size, size) * 0.1)
+        self.alpha_time_coeff = nn.Parameter(torch.randn(channels, size, size) * 0.001)
+        self.beta_time_coeff = nn.Parameter(torch.randn(channels, size, size) * 0.001)
+        self.channel_coupling = nn.Parameter(torch.eye(channels) * 0.01)
+        self.stability_eps = 1e-6
+        self.skip_weight = nn.Parameter(torch.tensor(0.9))
+
+    def forward(self, u):
+        original_u = u
+        for step in self._schedule():
+            u = self._diffuse(u, step)
+            u = F_.channel_mix(u, self.channel_coupling)
+        s = torch.sigmoid(self.skip_weight)
+        return s * original_u + (1 - s) * u
+
+
+class EnhancedDiffusionLayer(_AdiBase):
+    """cifar10.py:24-211: coefficients clamped to [eps,10], no smoothing, channel mixing before
+    every Strang step (cifar10.py:91).
+
+    ``channel_mixing_enabled=False`` (keyword only, not in the reference) skips the C x C
+    mixing product; the whole time loop then runs as ONE fused kernel launch.  It equals the
+    reference layer with ``channel_mixing`` set to the identity."""
+    _clamp_max = 10.0
+
+    def __init__(self, size=32, channels=3, dt=0.001, dx=1.0, dy=1.0, num_steps=10, *, channel_mixing_enabled=True):
+        super().__init__()
+        self.size, self.channels, self.dt, self.dx, self.dy, self.num_steps = size, channels, dt, dx, dy, num_steps
+        self.alpha_base = nn.Parameter(torch.ones(channels, size, size) * 1.0)
+        self.beta_base = nn.Parameter(torch.ones(channels, size, size) * 1.0)
+        self.alpha_time_coeff = nn.Parameter(torch.zeros(channels, size, size) * 0.1)
+        self.beta_time_coeff = nn.Parameter(torch.zeros(channels, size, size) * 0.1)
+        self.channel_mixing = nn.Parameter(torch.eye(channels) + torch.randn(channels, channels) * 0.01)
+        self.stability_eps = 1e-6
+        self.channel_mixing_enabled = channel_mixing_enabled
+        self._banner()
+
+    def _banner(self):
+        print(f"Alpha/Beta-Focused DiffusionLayer: {self.size}x{self.size}x{self.channels}")
+        print(f"  Spatial: dx={self.dx}, dy={self.dy}")
+        print(f"  Temporal: dt={self.dt}, steps={self.num_steps}")
+        print(f"  Learnable parameters: α matrices ({self.channels}x{self.size}x{self.size}), "
+              f"β matrices ({self.channels}x{self.size}x{self.size})")
+
+    def forward(self, u):
+        steps = self._schedule()
+        if not self.channel_mixing_enabled:
+            return self._diffuse(u, [s for step in steps for s in step])
+        for step in steps:
+            u = F_.channel_mix(u, self.channel_mixing)
+            u = self._diffuse(u, step)
+        return u
+
+
+class LearnableDiffusionLayer(EnhancedDiffusionLayer):
+    """cifar_2version.py:20-187: as EnhancedDiffusionLayer with the Lie split x(dt/2), y(dt/2)."""
+    _split = "lie"
+
+    def _banner(self):
+        print(f"Learnable Diffusion Layer: {self.size}x{self.size}x{self.channels}")
+        print(f"  Learnable α coefficients: {self.channels}x{self.size}x{self.size}")
+        print(f"  Learnable β coefficients: {self.channels}x{self.size}x{self.size}")
+        print(f"  Temporal: dt={self.dt}, steps={self.num_steps}")
+
+
+class ImprovedDiffusionLayer(nn.Module):
+    """tiny_imagenet.py:14-72 (the live part): per-channel scaled explicit 5-point step with a
+    0.1 relaxation.  ``beta_base`` exists but is unused, as in the reference (its grad is None).
+    The reference's training script reads ``model.diff.spatial_modulation`` (tiny_imagenet.py:614),
+    an attribute its own class never defines; it is not defined here either."""
+
+    def __init__(self, size=64, channels=3, dt=0.01, num_steps=1, use_implicit=False):
+        super().__init__()
+        self.size, self.channels, self.dt, self.num_steps, self.use_implicit = size, channels, dt, num_steps, use_implicit
+        self.alpha_base = nn.Parameter(torch.ones(channels) * 0.05)
+        self.beta_base = nn.Parameter(torch.ones(channels) * 0.05)
+        self.channel_scaling = nn.Parameter(torch.ones(channels))
+        self.stability_eps = 1e-6
+        self.max_coeff = 0.15
+
+    def forward(self, u):
+        for _ in range(self.num_steps):
+            u = F_.explicit5_step(u, self.alpha_base, self.channel_scaling, self.dt, self.stability_eps,
+                                  self.max_coeff, 0.1)
+        return u
+
+
+class PDELayer(nn.Module):
+    """emotion_recognition.py:56-97: reflect-pad once, Nt explicit Jacobi updates with separable
+    coefficients alpha(y) (rows) and beta(x) (columns) made from six scalars."""
+
+    def __init__(self, Nx=48, Ny=48, Lx=1.0, Ly=1.0, T=0.01, dt=0.001):
+        super().__init__()
+        self.Nx, self.Ny, self.Lx, self.Ly = Nx, Ny, Lx, Ly
+        self.T, self.dt = T, dt
+        self.dx = Lx / Nx
+        self.dy = Ly / Ny
+        self.Nt = int(T / dt)
+        self.alpha_w1 = nn.Parameter(torch.tensor(0.1))
+        self.alpha_w2 = nn.Parameter(torch.tensor(0.1))
+        self.alpha_w3 = nn.Parameter(torch.tensor(0.1))
+        self.beta_w1 = nn.Parameter(torch.tensor(0.3))
+        self.beta_w2 = nn.Parameter(torch.tensor(0.2))
+        self.beta_w3 = nn.Parameter(torch.tensor(0.2))
+        self.register_buffer("x", torch.linspace(0, Lx, Nx))
+        self.register_buffer("y", torch.linspace(0, Ly, Ny))
+
+    def alpha(self, y_val):
+        return 0.5 * self.dt * (self.alpha_w1 + self.alpha_w2 * torch.sin(2 * torch.pi * y_val)
+                                + self.alpha_w3 * torch.sin(4 * torch.pi * y_val)) / self.dx ** 2
+
+    def beta(self, x_val):
+        return self.dt * (self.beta_w1 + self.beta_w2 * torch.cos(2 * torch.pi * x_val)
+                          + self.beta_w3 * torch.cos(4 * torch.pi * x_val)) / self.dy ** 2
+
+    def forward(self, u0):
+        if u0.dim() != 4 or u0.shape[1] != 1:
+            raise ValueError(f"expected (B,1,H,W), got {tuple(u0.shape)}")
+        # coefficient vectors: alpha varies along dim 1 (rows), beta along dim 2 (columns)
+        out = F_.jacobi_diffuse(u0.squeeze(1), self.alpha(self.y), self.beta(self.x), self.Nt)
+        return out.unsqueeze(1)

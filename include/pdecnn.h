@@ -1,0 +1,165 @@
+/*
+ * pdecnn.h — C ABI of libpdecnn_hip.so: the MI355X (gfx950) implementation of the
+ * PDE diffusion-layer hot path of MariMamgo/CNN-with-PDE.
+ *
+ * Boundary.  The reference has no FFI; its boundary is the nn.Module surface of the
+ * layer classes.  This library is what a Python autograd.Function
+ * binds with ctypes; every entry point cites the reference code
+ * it replaces.  Conventions:
+ *   - plain pointers and sizes only; all tensor pointers are DEVICE pointers
+ *     (the caller owns every buffer), NCHW contiguous;
+ *   - every call enqueues work on `stream` (a hipStream_t passed as void*) and
+ *     returns immediately; no allocation, no synchronisation, no global state;
+ *   - return value: 0 on success, a negative PDE_E_* code otherwise (never throws).
+ */
+#ifndef PDECNN_H
+#define PDECNN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PDE_MAX_SWEEPS 96          /* e.g. 32 Strang steps */
+#define PDE_MAX_N 32               /* line length of the implicit layers (28, 32 in the reference) */
+
+#define PDE_OK 0
+#define PDE_E_BADARG (-1)          /* null pointer, non-positive dim, bad enum */
+#define PDE_E_UNSUPPORTED_N (-2)   /* N not a multiple of 4 or > PDE_MAX_N */
+#define PDE_E_TOO_MANY_SWEEPS (-3)
+#define PDE_E_LAUNCH (-4)          /* hipLaunch failed; hipGetLastError has details */
+#define PDE_E_WORKSPACE (-5)       /* workspace too small / misaligned */
+
+#define PDE_IO_F32 0
+#define PDE_IO_BF16 1
+
+#define PDE_AXIS_X 0               /* solve along W with alpha (mnist_test.py:67-98)  */
+#define PDE_AXIS_Y 1               /* solve along H with beta  (mnist_test.py:100-133) */
+
+/* One implicit (backward-Euler) sweep of the split scheme, in execution order.
+ * Mirrors one diffuse_x/diffuse_y call of the reference time loop
+ * (mnist_test.py:50-63, cifar10.py:86-110, cifar_2version.py:81-101). */
+typedef struct PdeSweep {
+    int32_t axis;       /* PDE_AXIS_X / PDE_AXIS_Y */
+    float   delta;      /* (float) time increment of this sweep: dt/2 or dt           */
+    float   h2;         /* (float) dx**2 or dy**2: coeff = theta*delta/h2              */
+    float   t;          /* (float) current_time at which alpha/beta are evaluated      */
+} PdeSweep;
+
+/* Static description of one fused run of sweeps over a (B,C,N,N) tensor. */
+typedef struct PdeAdiDesc {
+    int32_t B, C, N;            /* H = W = N                                             */
+    int32_t io_dtype;           /* PDE_IO_F32 | PDE_IO_BF16 (tensor I/O; math is fp32)   */
+    int32_t num_sweeps;
+    int32_t smooth3;            /* 1: 3-tap replicate average of the coefficient along the
+                                   solve axis (mnist_test.py:135-149)                     */
+    int32_t has_clamp_max;      /* 1: clamp(theta, eps, clamp_max) (cifar10.py:60-61)     */
+    float   clamp_max;
+    float   eps;                /* stability_eps: clamp floor AND the Thomas +eps          */
+    PdeSweep sweep[PDE_MAX_SWEEPS];
+} PdeAdiDesc;
+
+/* ---- K1: implicit ADI time-stepper -------------------- */
+
+/* Bytes of scratch the forward/backward calls need (256-byte aligned base expected). */
+size_t pde_adi_forward_workspace_bytes(const PdeAdiDesc* d);
+size_t pde_adi_backward_workspace_bytes(const PdeAdiDesc* d, int32_t num_checkpoints);
+
+/* y = (prod_s (A_s + eps I)^-1) u.  Replaces DiffusionLayer.forward's time loop with its
+ * diffuse_x/diffuse_y/thomas_solver_batch calls (mnist_test.py:44-198; cifar10.py:74-211
+ * without apply_channel_mixing, which is pde_channel_mix_*).
+ * alpha_xxx / beta_xxx: (C,N,N) fp32.  u, y: (B,C,N,N) of io_dtype; y must not alias u. */
+int pde_adi_forward(const PdeAdiDesc* d, const void* u, void* y,
+                    const float* alpha_base, const float* beta_base,
+                    const float* alpha_slope, const float* beta_slope,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* Exact reverse-mode derivative of pde_adi_forward (the reference gets it from autograd,
+ * SURVEY.md §3d).  Inputs: gy = dL/dy, y = forward output.  Outputs: gu = dL/du and the
+ * four parameter gradients (C,N,N) fp32 (overwritten, not accumulated).
+ * States needed for the coefficient gradients are rebuilt backwards from y
+ * (x_{s-1} = (A_s+eps I) x_s).  `ckpt_mask` bit s set means: do NOT rebuild the state
+ * after sweep s, read it from a checkpoint instead; the kernel then first recomputes the
+ * forward from `u` to write those checkpoints into the workspace.  ckpt_mask == 0 needs
+ * neither u nor checkpoint space (u may be NULL).  Bits are given low word first:
+ * sweep s is bit (s%64) of ckpt_mask[s/64]. */
+int pde_adi_backward(const PdeAdiDesc* d, const void* gy, const void* y, const void* u,
+                     const uint64_t ckpt_mask[2], void* gu,
+                     const float* alpha_base, const float* beta_base,
+                     const float* alpha_slope, const float* beta_slope,
+                     float* g_alpha_base, float* g_beta_base,
+                     float* g_alpha_slope, float* g_beta_slope,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* max over the tensor of coeff_s = theta_s*delta_s/h2_s for every sweep, written to
+ * kappa_max[num_sweeps] (device, fp32).  Host code uses it to choose ckpt_mask.  */
+int pde_adi_kappa_max(const PdeAdiDesc* d,
+                      const float* alpha_base, const float* beta_base,
+                      const float* alpha_slope, const float* beta_slope,
+                      float* kappa_max, void* stream);
+
+/* ---- channel operators ------------------------------------------ */
+
+/* out[b,i,p] = sum_j M[i,j] u[b,j,p]  — cifar10.py:65-72 apply_channel_mixing and
+ * SVHN.py:78-86 apply_channel_coupling (both reduce to this).  M: (C,C) fp32 row-major.
+ * u,out: (B,C,HW) of io_dtype; out must not alias u. */
+int pde_channel_mix_forward(int32_t B, int32_t C, int32_t HW, int32_t io_dtype,
+                            const void* u, const float* M, void* out, void* stream);
+/* gu[b,j,p] = sum_i M[i,j] gout[b,i,p];  gM[i,j] = sum_{b,p} gout[b,i,p] u[b,j,p].
+ * workspace: pde_channel_mix_backward_workspace_bytes(). */
+size_t pde_channel_mix_backward_workspace_bytes(int32_t B, int32_t C, int32_t HW);
+int pde_channel_mix_backward(int32_t B, int32_t C, int32_t HW, int32_t io_dtype,
+                             const void* u, const void* gout, const float* M,
+                             void* gu, float* gM,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- K2: explicit 5-point layers --------------------------- */
+
+/* tiny_imagenet.py:34-72, one relaxed explicit step:
+ *   a_c = clamp(alpha_base_c, eps, max_coeff);  v = s_c u;
+ *   out = u + relax*(v + a_c*dt*Lap0(v) - u)      (Lap0: zero ghost cells, padding=1)
+ * u,out: (B,C,H,W) of io_dtype. */
+int pde_explicit5_forward(int32_t B, int32_t C, int32_t H, int32_t W, int32_t io_dtype,
+                          const void* u, const float* alpha_base, const float* channel_scaling,
+                          float dt, float eps, float max_coeff, float relax,
+                          void* out, void* stream);
+size_t pde_explicit5_backward_workspace_bytes(int32_t B, int32_t C, int32_t H, int32_t W);
+/* gu, g_alpha_base (C), g_channel_scaling (C): overwritten. */
+int pde_explicit5_backward(int32_t B, int32_t C, int32_t H, int32_t W, int32_t io_dtype,
+                           const void* u, const void* gout,
+                           const float* alpha_base, const float* channel_scaling,
+                           float dt, float eps, float max_coeff, float relax,
+                           void* gu, float* g_alpha_base, float* g_channel_scaling,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* emotion_recognition.py:82-97: reflect-pad once, nt Jacobi updates of the interior with
+ * row coefficients a_row[H] (multiplying the second difference along H) and column
+ * coefficients b_col[W] (along W); the padded ring keeps its initial values.
+ * u,out: (B,H,W) fp32 (the layer is single-channel).  H,W <= 64. */
+int pde_jacobi_forward(int32_t B, int32_t H, int32_t W, int32_t nt,
+                       const float* u, const float* a_row, const float* b_col,
+                       float* out, void* stream);
+size_t pde_jacobi_backward_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t nt);
+/* gu (B,H,W), g_a_row[H], g_b_col[W]: overwritten. */
+int pde_jacobi_backward(int32_t B, int32_t H, int32_t W, int32_t nt,
+                        const float* u, const float* gout,
+                        const float* a_row, const float* b_col,
+                        float* gu, float* g_a_row, float* g_b_col,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- utilities ------------------------------------------------------------------------- */
+
+/* Average device time (ms) per launch of the dominant kernel of the most recent
+ * pde_adi_forward / pde_adi_backward issued with timing enabled; measured with HIP
+ * events recorded on the stream the kernel was launched on.  bench.py's roofline leg. */
+int pde_timing_enable(int32_t on);
+int pde_timing_read(double* fwd_ms_sum, int64_t* fwd_launches, double* bwd_ms_sum, int64_t* bwd_launches);
+
+const char* pde_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PDECNN_H */
