@@ -1,7 +1,7 @@
 """Public surface of cnn_with_pde_amd."""
 from . import _lib
 from ._lib import PdeError, LIB_PATH
-from .functional import (Sweep, adi_schedule, adi_diffuse, channel_mix, explicit5_step, jacobi_diffuse,
+from .functional import (Sweep, adi_schedule, adi_diffuse, plan_checkpoints, channel_mix, explicit5_step, jacobi_diffuse,
                          timing_enable, timing_read)
 from .layers import (MnistDiffusionLayer, FashionDiffusionLayer, SvhnDiffusionLayer, EnhancedDiffusionLayer,
                      LearnableDiffusionLayer, ImprovedDiffusionLayer, PDELayer)
@@ -22,7 +22,7 @@ def library_version() -> str:
     return _lib.load().pde_version().decode()
 
 
-__all__ = ["PdeError", "LIB_PATH", "Sweep", "adi_schedule", "adi_diffuse", "channel_mix", "explicit5_step",
+__all__ = ["PdeError", "LIB_PATH", "Sweep", "adi_schedule", "adi_diffuse", "plan_checkpoints", "channel_mix", "explicit5_step",
            "jacobi_diffuse", "timing_enable", "timing_read", "MnistDiffusionLayer", "FashionDiffusionLayer",
            "SvhnDiffusionLayer", "EnhancedDiffusionLayer", "LearnableDiffusionLayer", "ImprovedDiffusionLayer",
            "PDELayer", "REFERENCE_CLASSES", "library_version"]

@@ -56,6 +56,8 @@ struct SweepTab {
 
 struct FactorArgs {
     SweepTab* tab;
+    int* varying;           // [C] set to 1 when a clamp mask of the channel differs between sweeps (may be null)
+    float t_first[2];       // time of the earliest sweep of each axis
     const float* ab;
     const float* bb;
     const float* as;
@@ -86,10 +88,23 @@ __global__ __launch_bounds__(64) void adi_factor_kernel(FactorArgs a) {
         a.tab->first_s[ax] = first;
         a.tab->t_last[ax] = tlast;
     }
-    const int line = idx % N;
-    const int c = (idx / N) % a.C;
-    const int s = idx / (N * a.C);
+    const int line = idx % 32;
+    const int c = (idx / 32) % a.C;
+    const int s = idx / (32 * a.C);
     if (s >= a.S) return;
+    if (line >= N) {
+        // lanes beyond the plane run the same instruction stream on zeros: give them finite
+        // (zero) coefficients so that nothing they compute can leak a NaN through a lane exchange
+        float* rec = a.coef + ((size_t)s * a.C + c) * kRecStride;
+        rec[kRecJn + line] = 0.f;
+        for (int i = 0; i < kLineStride; ++i) {
+            rec[kRecInv + line * kLineStride + i] = 0.f;
+            rec[kRecE + line * kLineStride + i] = 0.f;
+            rec[kRecKapX + line * kLineStride + i] = 0.f;
+            rec[kRecMaskX + line * kLineStride + i] = 0.f;
+        }
+        return;
+    }
     const PdeSweep sw = a.sweep[s];
     const bool xax = sw.axis == PDE_AXIS_X;
     const float* base = xax ? a.ab : a.bb;
@@ -99,13 +114,22 @@ __global__ __launch_bounds__(64) void adi_factor_kernel(FactorArgs a) {
     const int o0 = xax ? line * N : line;
 
     float kap[PDE_MAX_N];
+    float pass[PDE_MAX_N];
+    bool differs = false;
     // theta = clamp(base + slope*t, eps[, max])          mnist_test.py:33-42
     for (int i = 0; i < N; ++i) {
-        float th = base[cbase + o0 + i * st] + slope[cbase + o0 + i * st] * sw.t;
+        const float bs = base[cbase + o0 + i * st], sl = slope[cbase + o0 + i * st];
+        float th = bs + sl * sw.t;
+        const bool ps = (th >= a.eps) && (!a.has_max || th <= a.cmax);     // clamp passes the gradient
+        const float th0 = bs + sl * a.t_first[sw.axis];
+        const bool ps0 = (th0 >= a.eps) && (!a.has_max || th0 <= a.cmax);
+        differs |= (ps != ps0);
+        pass[i] = ps ? 1.0f : 0.0f;
         th = fmaxf(th, a.eps);
         if (a.has_max) th = fminf(th, a.cmax);
         kap[i] = th;
     }
+    if (differs && a.varying) atomicOr(&a.varying[c], 1);
     if (a.smooth3) {                             // mnist_test.py:135-149 (replicate ends)
         const float third = 1.0f / 3.0f;
         float prev = kap[0];
@@ -121,9 +145,8 @@ __global__ __launch_bounds__(64) void adi_factor_kernel(FactorArgs a) {
         kap[i] = (kap[i] * sw.delta) / sw.h2;
         km = fmaxf(km, kap[i]);
     }
-    if (a.kmax) atomicMax((unsigned int*)&a.kmax[s], __float_as_uint(km));   // kap > 0
 
-    float* rec = a.coef + ((size_t)s * a.C + c) * kRecAll;
+    float* rec = a.coef + ((size_t)s * a.C + c) * kRecStride;
     float* inv_row = rec + kRecInv + line * kLineStride;
     float* e_row = rec + kRecE + line * kLineStride;
     float e_in[2];
@@ -148,12 +171,52 @@ __global__ __launch_bounds__(64) void adi_factor_kernel(FactorArgs a) {
     rec[kRecJn + line] = 1.0f / (1.0f - e_in[0] * e_in[1]);
     // kappa in row layout (always): element (h,w) at row h, half_pos(w)
     float* kx = rec + kRecKapX;
+    float* mx = rec + kRecMaskX;
     if (xax) {
-        for (int i = 0; i < N; ++i) kx[line * kLineStride + half_pos(i, N)] = kap[i];
+        for (int i = 0; i < N; ++i) {
+            kx[line * kLineStride + half_pos(i, N)] = kap[i];
+            mx[line * kLineStride + half_pos(i, N)] = pass[i];
+        }
     } else {
         const int p = half_pos(line, N);
-        for (int i = 0; i < N; ++i) kx[i * kLineStride + p] = kap[i];
+        for (int i = 0; i < N; ++i) {
+            kx[i * kLineStride + p] = kap[i];
+            mx[i * kLineStride + p] = pass[i];
+        }
     }
+}
+
+// max over the tensor of the coefficient of every sweep (no factorisation): feeds the host-side
+// choice of checkpoints.  One thread per (sweep, channel, line).
+__global__ __launch_bounds__(64) void adi_kmax_kernel(FactorArgs a) {
+    const int idx = blockIdx.x * 64 + threadIdx.x;
+    const int N = a.N;
+    const int line = idx % 32;
+    const int c = (idx / 32) % a.C;
+    const int s = idx / (32 * a.C);
+    if (s >= a.S || line >= N) return;
+    const PdeSweep sw = a.sweep[s];
+    const bool xax = sw.axis == PDE_AXIS_X;
+    const float* base = xax ? a.ab : a.bb;
+    const float* slope = xax ? a.as : a.bs;
+    const size_t cbase = (size_t)c * N * N;
+    const int st = xax ? 1 : N;
+    const int o0 = xax ? line * N : line;
+    float th[PDE_MAX_N];
+    for (int i = 0; i < N; ++i) {
+        float v = base[cbase + o0 + i * st] + slope[cbase + o0 + i * st] * sw.t;
+        v = fmaxf(v, a.eps);
+        if (a.has_max) v = fminf(v, a.cmax);
+        th[i] = v;
+    }
+    float km = 0.f;
+    const float third = 1.0f / 3.0f;
+    for (int i = 0; i < N; ++i) {
+        float v = th[i];
+        if (a.smooth3) v = (th[i > 0 ? i - 1 : 0] * third + th[i] * third) + th[i + 1 < N ? i + 1 : N - 1] * third;
+        km = fmaxf(km, (v * sw.delta) / sw.h2);
+    }
+    atomicMax((unsigned int*)&a.kmax[s], __float_as_uint(km));            // coefficients are > 0
 }
 
 // ------------------------------------------------------------------------------------
@@ -169,6 +232,12 @@ struct SweepArgs {
     const float* coef;      // [S][C][kRecAll]
     float* part;            // bwd: [G][C][4][kImage] partial parameter-gradient sums
     const SweepTab* tab;
+    const int* varying;     // bwd: [C] per-channel "clamp mask changes with time" flag
+    const void* in2;        // bwd with checkpoints: u
+    float* ckpt;            // bwd with checkpoints: [slots][B][C][N][N] fp32
+    unsigned long long ck[2];   // bit s: the state after sweep s is checkpointed
+    int Sf;                 // bwd: sweeps 0..Sf-1 are recomputed forward first (0: no checkpoints)
+    int smooth3;
     int B, C, S, G;
     float one_eps;          // 1 + eps
 };
@@ -184,18 +253,31 @@ __device__ __forceinline__ float dpp_move(float v) {
 constexpr int kDppWaveShl1 = 0x130;   // lane i <- lane i+1
 constexpr int kDppWaveShr1 = 0x138;   // lane i <- lane i-1
 
-// Stage COUNT floats of a coefficient record global -> registers -> LDS: two 16-byte pieces
-// per thread at most, held in plain locals of the kernel (a struct here ends up in scratch).
+// Stage COUNT floats of a coefficient record global -> registers -> LDS: up to three 16-byte
+// pieces per thread, held in plain locals of the kernel (a struct here ends up in scratch).
+struct Staged { float4 r0, r1, r2; };
 template <int COUNT>
-__device__ __forceinline__ void stage_load(const float* src, int tid, float4& r0, float4& r1) {
-    static_assert(COUNT / 4 <= 2 * kThreads, "record too large for two pieces per thread");
+__device__ __forceinline__ void stage_load(const float* src, int tid, float4& r0, float4& r1, float4& r2) {
+    constexpr int F4 = COUNT / 4;
+    static_assert(F4 <= 3 * kThreads, "record too large for three pieces per thread");
     r0 = reinterpret_cast<const float4*>(src)[tid];
-    if (tid + kThreads < COUNT / 4) r1 = reinterpret_cast<const float4*>(src)[tid + kThreads];
+    if constexpr (F4 > kThreads) {
+        if (F4 >= 2 * kThreads || tid + kThreads < F4) r1 = reinterpret_cast<const float4*>(src)[tid + kThreads];
+    }
+    if constexpr (F4 > 2 * kThreads) {
+        if (tid + 2 * kThreads < F4) r2 = reinterpret_cast<const float4*>(src)[tid + 2 * kThreads];
+    }
 }
 template <int COUNT>
-__device__ __forceinline__ void stage_store(float* dst, int tid, const float4& r0, const float4& r1) {
+__device__ __forceinline__ void stage_store(float* dst, int tid, const float4& r0, const float4& r1, const float4& r2) {
+    constexpr int F4 = COUNT / 4;
     reinterpret_cast<float4*>(dst)[tid] = r0;
-    if (tid + kThreads < COUNT / 4) reinterpret_cast<float4*>(dst)[tid + kThreads] = r1;
+    if constexpr (F4 > kThreads) {
+        if (F4 >= 2 * kThreads || tid + kThreads < F4) reinterpret_cast<float4*>(dst)[tid + kThreads] = r1;
+    }
+    if constexpr (F4 > 2 * kThreads) {
+        if (tid + 2 * kThreads < F4) reinterpret_cast<float4*>(dst)[tid + 2 * kThreads] = r2;
+    }
 }
 
 // ---- plane I/O through the wave's LDS image (natural [h][w] rows, stride 36) --------
@@ -399,6 +481,11 @@ __device__ __forceinline__ void solve_fwd(float (&v)[J][M], const float* rec, in
     }
 }
 
+__device__ __forceinline__ int ck_slot(const unsigned long long (&ck)[2], int s) {
+    return s < 64 ? __builtin_popcountll(ck[0] & ((1ull << s) - 1ull))
+                  : __builtin_popcountll(ck[0]) + __builtin_popcountll(ck[1] & ((1ull << (s - 64)) - 1ull));
+}
+
 template <int N, int J, typename IO>
 __global__ __launch_bounds__(kThreads) void adi_fwd_kernel(SweepArgs a) {
     constexpr int M = Geo<N>::M;
@@ -415,10 +502,12 @@ __global__ __launch_bounds__(kThreads) void adi_fwd_kernel(SweepArgs a) {
     const int nchunk = (a.B + PPI - 1) / PPI;
     const size_t plane = (size_t)N * N;
 
-    float4 st0 = make_float4(0.f, 0.f, 0.f, 0.f), st1 = st0;
+    // rows >= N of the wave images are never written: zero them once so idle lanes read zeros
+    for (int e = tid; e < kWaves * kImage; e += kThreads) tbuf[e] = 0.f;
+    float4 st0 = make_float4(0.f, 0.f, 0.f, 0.f), st1 = st0, st2 = st0;
     unsigned n = 0;                                       // running sweep counter (buffer parity)
-    stage_load<kRecFwd>(a.coef + ((size_t)0 * a.C + c) * kRecAll, tid, st0, st1);
-    stage_store<kRecFwd>(cbuf, tid, st0, st1);
+    stage_load<kRecFwd>(a.coef + ((size_t)0 * a.C + c) * kRecStride, tid, st0, st1, st2);
+    stage_store<kRecFwd>(cbuf, tid, st0, st1, st2);
     __syncthreads();
 
     for (int q = g; q < nchunk; q += a.G) {
@@ -437,7 +526,7 @@ __global__ __launch_bounds__(kThreads) void adi_fwd_kernel(SweepArgs a) {
         for (int s = 0; s < a.S; ++s, ++n) {
             const int snext = (s + 1 < a.S) ? s + 1 : 0;
             const bool pre = (s + 1 < a.S) || more;
-            if (pre) stage_load<kRecFwd>(a.coef + ((size_t)snext * a.C + c) * kRecAll, tid, st0, st1);
+            if (pre) stage_load<kRecFwd>(a.coef + ((size_t)snext * a.C + c) * kRecStride, tid, st0, st1, st2);
             const float* rec = cbuf + (n & 1) * kRecFwd;
             const int axs = a.tab->axis[s];
             if (axs == PDE_AXIS_Y) {
@@ -449,13 +538,23 @@ __global__ __launch_bounds__(kThreads) void adi_fwd_kernel(SweepArgs a) {
 #pragma unroll
                 for (int j = 0; j < J; ++j) relayout<N>(v[j], T, l, hf);
             }
-            if (pre) stage_store<kRecFwd>(cbuf + ((n + 1) & 1) * kRecFwd, tid, st0, st1);
+            if ((a.ck[s >> 6] >> (s & 63)) & 1ull) {      // backward pre-pass: park this state (fp32)
+                float* slot = a.ckpt + (size_t)ck_slot(a.ck, s) * a.B * a.C * plane;
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    const int b = q * PPI + wave * J + j;
+                    rows_to_plane<N, float>(v[j], T, lane, l, hf, slot + ((size_t)b * a.C + c) * plane, b < a.B);
+                }
+            }
+            if (pre) stage_store<kRecFwd>(cbuf + ((n + 1) & 1) * kRecFwd, tid, st0, st1, st2);
             __syncthreads();
         }
+        if (y != nullptr) {
 #pragma unroll
-        for (int j = 0; j < J; ++j) {
-            const int b = q * PPI + wave * J + j;
-            rows_to_plane<N, IO>(v[j], T, lane, l, hf, y + ((size_t)b * a.C + c) * plane, b < a.B);
+            for (int j = 0; j < J; ++j) {
+                const int b = q * PPI + wave * J + j;
+                rows_to_plane<N, IO>(v[j], T, lane, l, hf, y + ((size_t)b * a.C + c) * plane, b < a.B);
+            }
         }
     }
 }
@@ -464,9 +563,9 @@ __global__ __launch_bounds__(kThreads) void adi_fwd_kernel(SweepArgs a) {
 // adjoint two-sided solve (A + eps I)^T g = r on J planes, in place.
 template <int M, int J>
 __device__ __forceinline__ void solve_adj(float (&r)[J][M], const float* rec, int l, int hf) {
-    float e[M], inv[M];
+    __builtin_amdgcn_sched_barrier(0);
+    float e[M];
     load_half<M>(rec + kRecE + l * kLineStride + hf * kHalfPad, e);
-    load_half<M>(rec + kRecInv + l * kLineStride + hf * kHalfPad, inv);
     const float jn = rec[kRecJn + l];
     // H_k = r_k + e_{k-1} H_{k-1}
 #pragma unroll
@@ -486,44 +585,73 @@ __device__ __forceinline__ void solve_adj(float (&r)[J][M], const float* rec, in
 #pragma unroll
         for (int j = 0; j < J; ++j) r[j][k] = fmaf(e[k + 1], r[j][k + 1], r[j][k]);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    float inv[M];
+    load_half<M>(rec + kRecInv + l * kLineStride + hf * kHalfPad, inv);
 #pragma unroll
     for (int k = 0; k < M; ++k) {
 #pragma unroll
         for (int j = 0; j < J; ++j) r[j][k] *= inv[k];
     }
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // After an x sweep has been undone on the adjoint (g in r[]), use the sweep's OUTPUT state
 // x to (1) add g.(Lx) to the coefficient-gradient sums, (2) rebuild the sweep's input
 // x_prev = (1+eps) x + kap.(Lx).  L = Neumann second difference along the row.
-template <int M, int J>
+// MASKED: the clamp mask of this channel changes with time, so the sum over sweeps cannot be
+// masked (and un-smoothed) once at the end: do both here, per sweep.
+template <int M, int J, bool MASKED>
 __device__ __forceinline__ void state_x(const float (&g)[J][M], float (&x)[J][M], float (&acc)[M],
-                                        const float* rec, int l, int hf, float one_eps) {
+                                        const float* rec, int l, int hf, float one_eps, int smooth) {
     float kap[M];
     load_half<M>(rec + kRecKapX + l * kLineStride + hf * kHalfPad, kap);
+    float msk[MASKED ? M : 1];
+    if constexpr (MASKED) load_half<M>(rec + kRecMaskX + l * kLineStride + hf * kHalfPad, msk);
 #pragma unroll
     for (int j = 0; j < J; ++j) {
+        float gq[MASKED ? M : 1];
         float xo_next = xchg_half(x[j][M - 1]);          // inner neighbour of k = M-1
 #pragma unroll
         for (int k = M - 1; k >= 0; --k) {
             const float xo = x[j][k];
             float q = (k == 0) ? xo - xo_next : fmaf(2.0f, xo, -x[j][k - 1]) - xo_next;
-            acc[k] = fmaf(g[j][k], q, acc[k]);
+            if constexpr (MASKED) gq[k] = g[j][k] * q;
+            else acc[k] = fmaf(g[j][k], q, acc[k]);
             x[j][k] = fmaf(kap[k], q, xo * one_eps);
             xo_next = xo;
+        }
+        if constexpr (MASKED) {
+            if (smooth) {                                // transpose of the replicate 3-tap average (x1/3 later)
+                const float gin = xchg_half(gq[M - 1]);
+#pragma unroll
+                for (int k = 0; k < M; ++k) {
+                    float z = (k == 0) ? 2.0f * gq[0] : gq[k] + gq[k - 1];
+                    z += (k < M - 1) ? gq[k + 1] : gin;
+                    acc[k] = fmaf(msk[k], z, acc[k]);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < M; ++k) acc[k] = fmaf(msk[k], gq[k], acc[k]);
+            }
         }
     }
 }
 
-// Same for a y sweep, with the state (and g) in ROW layout: the second difference runs
-// across lanes (rows h-1, h+1 = lanes l-1, l+1 of the same half).
-template <int N, int J>
+// Same for a y sweep, with the state (and g) in ROW layout: the second difference (and, when
+// MASKED, the transposed smoothing) runs across lanes (rows h-1, h+1 = lanes l-1, l+1 of the
+// same half).
+template <int N, int J, bool MASKED>
 __device__ __forceinline__ void state_y(const float (&g)[J][N / 2], float (&x)[J][N / 2], float (&acc)[N / 2],
-                                        const float* rec, int l, int hf, float one_eps) {
+                                        const float* rec, int l, int hf, float one_eps, int smooth) {
     constexpr int M = N / 2;
     float kap[M];
     load_half<M>(rec + kRecKapX + l * kLineStride + hf * kHalfPad, kap);
-    const float kk = (l == 0 || l == N - 1) ? 1.0f : 2.0f;
+    float msk[MASKED ? M : 1];
+    if constexpr (MASKED) load_half<M>(rec + kRecMaskX + l * kLineStride + hf * kHalfPad, msk);
+    const bool edge = (l == 0 || l == N - 1);
+    const float kk = edge ? 1.0f : 2.0f;
+    const float kz = edge ? 2.0f : 1.0f;
     const float mu = (l > 0) ? 1.0f : 0.0f;
     const float md = (l < N - 1) ? 1.0f : 0.0f;
 #pragma unroll
@@ -536,21 +664,50 @@ __device__ __forceinline__ void state_y(const float (&g)[J][N / 2], float (&x)[J
             float q = kk * xo;
             q = fmaf(-mu, up, q);
             q = fmaf(-md, dn, q);
-            acc[k] = fmaf(g[j][k], q, acc[k]);
+            if constexpr (MASKED) {
+                const float gq = g[j][k] * q;
+                float z = gq;
+                if (smooth) {
+                    const float zu = dpp_move<kDppWaveShr1>(gq);
+                    const float zd = dpp_move<kDppWaveShl1>(gq);
+                    z = kz * gq;
+                    z = fmaf(mu, zu, z);
+                    z = fmaf(md, zd, z);
+                }
+                acc[k] = fmaf(msk[k], z, acc[k]);
+            } else {
+                acc[k] = fmaf(g[j][k], q, acc[k]);
+            }
             x[j][k] = fmaf(kap[k], q, xo * one_eps);
         }
     }
 }
 
 template <int N, int J, typename IO>
+__device__ __forceinline__ void load_planes(const IO* base, int q, int wave, int lane, int l, int hf, int B, int C,
+                                            int c, float* T, float (&v)[J][N / 2]) {
+    constexpr int PPI = kWaves * J;
+    float4 raw[J][Geo<N>::kLoads];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int b = q * PPI + wave * J + j;
+        plane_fetch<N, IO>(base + ((size_t)b * C + c) * (size_t)(N * N), b < B, lane, raw[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) plane_to_rows<N>(raw[j], T, lane, l, hf, v[j]);
+}
+
+template <int N, int J, typename IO, bool MASKED>
 __global__ __launch_bounds__(kThreads) void adi_bwd_kernel(SweepArgs a) {
     constexpr int M = Geo<N>::M;
+    constexpr int REC = MASKED ? kRecStride : kRecBwd;
+    const int c = blockIdx.x % a.C, g = blockIdx.x / a.C;
+    if ((a.varying[c] != 0) != MASKED) return;            // the other instantiation owns this channel
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* cbuf = smem;                                   // [2][kRecAll]
-    float* tbuf = smem + 2 * kRecAll;                     // [kWaves][kImage]
+    float* cbuf = smem;                                   // [2][REC]
+    float* tbuf = smem + 2 * REC;                         // [kWaves][kImage]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hf = lane >> 5, l = lane & 31;
-    const int c = blockIdx.x % a.C, g = blockIdx.x / a.C;
     float* T = tbuf + wave * kImage;
     const IO* gy = static_cast<const IO*>(a.in0);
     const IO* yy = static_cast<const IO*>(a.in1);
@@ -558,36 +715,23 @@ __global__ __launch_bounds__(kThreads) void adi_bwd_kernel(SweepArgs a) {
     constexpr int PPI = kWaves * J;
     const int nchunk = (a.B + PPI - 1) / PPI;
     const size_t plane = (size_t)N * N;
+    auto ck_bit = [&](int s) { return (int)((a.ck[s >> 6] >> (s & 63)) & 1ull); };
 
     float Ax[M], Tx[M], Ay[M], Ty[M];
 #pragma unroll
     for (int k = 0; k < M; ++k) Ax[k] = Tx[k] = Ay[k] = Ty[k] = 0.f;
 
-    float4 st0 = make_float4(0.f, 0.f, 0.f, 0.f), st1 = st0;
+    for (int e = tid; e < kWaves * kImage; e += kThreads) tbuf[e] = 0.f;
+    float4 st0 = make_float4(0.f, 0.f, 0.f, 0.f), st1 = st0, st2 = st0;
     unsigned n = 0;
-    stage_load<kRecAll>(a.coef + ((size_t)(a.S - 1) * a.C + c) * kRecAll, tid, st0, st1);
-    stage_store<kRecAll>(cbuf, tid, st0, st1);
+    stage_load<REC>(a.coef + ((size_t)(a.S - 1) * a.C + c) * kRecStride, tid, st0, st1, st2);
+    stage_store<REC>(cbuf, tid, st0, st1, st2);
     __syncthreads();
 
     for (int q = g; q < nchunk; q += a.G) {
         float r[J][M], x[J][M];
-        {
-            float4 raw[J][Geo<N>::kLoads];
-#pragma unroll
-            for (int j = 0; j < J; ++j) {
-                const int b = q * PPI + wave * J + j;
-                plane_fetch<N, IO>(gy + ((size_t)b * a.C + c) * plane, b < a.B, lane, raw[j]);
-            }
-#pragma unroll
-            for (int j = 0; j < J; ++j) plane_to_rows<N>(raw[j], T, lane, l, hf, r[j]);
-#pragma unroll
-            for (int j = 0; j < J; ++j) {
-                const int b = q * PPI + wave * J + j;
-                plane_fetch<N, IO>(yy + ((size_t)b * a.C + c) * plane, b < a.B, lane, raw[j]);
-            }
-#pragma unroll
-            for (int j = 0; j < J; ++j) plane_to_rows<N>(raw[j], T, lane, l, hf, x[j]);
-        }
+        load_planes<N, J, IO>(gy, q, wave, lane, l, hf, a.B, a.C, c, T, r);
+        load_planes<N, J, IO>(yy, q, wave, lane, l, hf, a.B, a.C, c, T, x);
         // The time-weighted sums use summation by parts over the whole processing sequence
         // (all chunks, sweeps in decreasing time):  sum_i tau_i G_i = sum_i (tau_i - tau_{i+1}) R_i
         // with R_i the running sum of g.q and tau_{i+1} the time of the next processed sweep of
@@ -596,8 +740,8 @@ __global__ __launch_bounds__(kThreads) void adi_bwd_kernel(SweepArgs a) {
         for (int s = a.S - 1; s >= 0; --s, ++n) {
             const int snext = (s > 0) ? s - 1 : a.S - 1;
             const bool pre = (s > 0) || more;
-            if (pre) stage_load<kRecAll>(a.coef + ((size_t)snext * a.C + c) * kRecAll, tid, st0, st1);
-            const float* rec = cbuf + (n & 1) * kRecAll;
+            if (pre) stage_load<REC>(a.coef + ((size_t)snext * a.C + c) * kRecStride, tid, st0, st1, st2);
+            const float* rec = cbuf + (n & 1) * REC;
             const int axs = a.tab->axis[s];
             float dts = a.tab->dts[s];
             if (more && s == a.tab->first_s[axs]) dts -= a.tab->t_last[axs];
@@ -607,20 +751,25 @@ __global__ __launch_bounds__(kThreads) void adi_bwd_kernel(SweepArgs a) {
                 solve_adj<M, J>(r, rec, l, hf);
 #pragma unroll
                 for (int j = 0; j < J; ++j) relayout<N>(r[j], T, l, hf);
-                state_y<N, J>(r, x, Ay, rec, l, hf, a.one_eps);
+                state_y<N, J, MASKED>(r, x, Ay, rec, l, hf, a.one_eps, a.smooth3);
                 if (dts != 0.f) {
 #pragma unroll
                     for (int k = 0; k < M; ++k) Ty[k] = fmaf(dts, Ay[k], Ty[k]);
                 }
             } else {
                 solve_adj<M, J>(r, rec, l, hf);
-                state_x<M, J>(r, x, Ax, rec, l, hf, a.one_eps);
+                state_x<M, J, MASKED>(r, x, Ax, rec, l, hf, a.one_eps, a.smooth3);
                 if (dts != 0.f) {
 #pragma unroll
                     for (int k = 0; k < M; ++k) Tx[k] = fmaf(dts, Ax[k], Tx[k]);
                 }
             }
-            if (pre) stage_store<kRecAll>(cbuf + ((n + 1) & 1) * kRecAll, tid, st0, st1);
+            // x now holds the rebuilt state after sweep s-1; take the checkpoint instead if there is one
+            if (s > 0 && ck_bit(s - 1)) {
+                const float* slot = a.ckpt + (size_t)ck_slot(a.ck, s - 1) * a.B * a.C * plane;
+                load_planes<N, J, float>(slot, q, wave, lane, l, hf, a.B, a.C, c, T, x);
+            }
+            if (pre) stage_store<REC>(cbuf + ((n + 1) & 1) * REC, tid, st0, st1, st2);
             __syncthreads();
         }
 #pragma unroll
@@ -660,13 +809,13 @@ struct PgradArgs {
     float* g_bb;
     float* g_as;
     float* g_bs;
-    int* flags;             // [0] set to 1 when a clamp mask differs between sweeps (unsupported fast path)
+    const int* varying;     // [C] 1: the masked kernel already applied mask and transposed smoothing per sweep
     int C, N, S, G;
     int smooth3, has_max, accumulate;
     float cmax, eps;
     float wx, wy;           // delta/h2 of the x / y sweeps
-    unsigned char axis[PDE_MAX_SWEEPS];
-    float t[PDE_MAX_SWEEPS];
+    float t_first[2];
+    int have_axis[2];
 };
 
 __global__ __launch_bounds__(1024) void adi_pgrad_kernel(PgradArgs a) {
@@ -692,7 +841,11 @@ __global__ __launch_bounds__(1024) void adi_pgrad_kernel(PgradArgs a) {
         {
             const float(*A)[PDE_MAX_N + 1] = sm[2 * ax];
             const float(*Tm)[PDE_MAX_N + 1] = sm[2 * ax + 1];
-            if (a.smooth3) {
+            if (a.varying[c]) {
+                const float f = a.smooth3 ? wgt * (1.0f / 3.0f) : wgt;
+                gb = A[h][w] * f;
+                gs = Tm[h][w] * f;
+            } else if (a.smooth3) {
                 // transpose of the replicate-padded 3-tap average along the solve axis:
                 // theta_bar_j = (1/3)(c_j q_j + q_{j-1} + q_{j+1}),  c_j = 2 at the two ends, else 1
                 const int i = (ax == 0) ? w : h;
@@ -708,20 +861,14 @@ __global__ __launch_bounds__(1024) void adi_pgrad_kernel(PgradArgs a) {
                 gs = Tm[h][w] * wgt;
             }
         }
-        // clamp pass-through mask; this fast path needs it to be the same for every sweep
-        const float base = (ax == 0 ? a.ab : a.bb)[off];
-        const float slope = (ax == 0 ? a.as : a.bs)[off];
-        int first = -1;
-        bool varying = false;
-        for (int s = 0; s < a.S; ++s) {
-            if (a.axis[s] != ax) continue;
-            const float th = base + slope * a.t[s];
-            const int pass = (th >= a.eps) && (!a.has_max || th <= a.cmax);
-            if (first < 0) first = pass;
-            else if (pass != first) varying = true;
+        // clamp pass-through mask, the same for every sweep of a channel that gets here unflagged
+        if (!a.varying[c]) {
+            const float base = (ax == 0 ? a.ab : a.bb)[off];
+            const float slope = (ax == 0 ? a.as : a.bs)[off];
+            const float th = base + slope * a.t_first[ax];
+            const bool pass = (th >= a.eps) && (!a.has_max || th <= a.cmax);
+            if (!pass || !a.have_axis[ax]) { gb = 0.f; gs = 0.f; }
         }
-        if (varying) atomicOr(a.flags, 1);
-        if (first <= 0) { gb = 0.f; gs = 0.f; }
         float* ob = (ax == 0) ? a.g_ab : a.g_bb;
         float* os = (ax == 0) ? a.g_as : a.g_bs;
         if (a.accumulate) { ob[off] += gb; os[off] += gs; }
@@ -745,8 +892,11 @@ int check_desc(const PdeAdiDesc* d) {
     return PDE_OK;
 }
 
-size_t coef_bytes(const PdeAdiDesc* d) { return align_up((size_t)d->num_sweeps * d->C * kRecAll * sizeof(float), 256); }
+size_t coef_bytes(const PdeAdiDesc* d) {
+    return align_up((size_t)d->num_sweeps * d->C * kRecStride * sizeof(float), 256);
+}
 size_t tab_bytes() { return align_up(sizeof(SweepTab), 256); }
+size_t flag_bytes(const PdeAdiDesc* d) { return align_up((size_t)d->C * sizeof(int), 256); }
 
 constexpr int kJFwd = 4;
 constexpr int kJBwd = 1;
@@ -759,15 +909,27 @@ int groups_per_channel(const PdeAdiDesc* d, int planes_per_iter, int wg_per_cu) 
     return G;
 }
 
-int launch_factor(const PdeAdiDesc* d, const float* ab, const float* bb, const float* as, const float* bs,
-                  float* coef, SweepTab* tab, float* kmax, hipStream_t st) {
-    FactorArgs fa;
-    fa.tab = tab;
-    fa.ab = ab; fa.bb = bb; fa.as = as; fa.bs = bs; fa.coef = coef; fa.kmax = kmax;
+void fill_factor_args(FactorArgs& fa, const PdeAdiDesc* d, const float* ab, const float* bb, const float* as,
+                      const float* bs) {
+    fa.tab = nullptr; fa.varying = nullptr; fa.coef = nullptr; fa.kmax = nullptr;
+    fa.ab = ab; fa.bb = bb; fa.as = as; fa.bs = bs;
     fa.C = d->C; fa.N = d->N; fa.S = d->num_sweeps;
     fa.smooth3 = d->smooth3; fa.has_max = d->has_clamp_max; fa.cmax = d->clamp_max; fa.eps = d->eps;
-    for (int s = 0; s < d->num_sweeps; ++s) fa.sweep[s] = d->sweep[s];
-    const int total = d->num_sweeps * d->C * d->N;
+    fa.t_first[0] = fa.t_first[1] = 0.f;
+    bool seen[2] = {false, false};
+    for (int s = 0; s < d->num_sweeps; ++s) {
+        fa.sweep[s] = d->sweep[s];
+        const int ax = d->sweep[s].axis;
+        if (!seen[ax]) { seen[ax] = true; fa.t_first[ax] = d->sweep[s].t; }
+    }
+}
+
+int launch_factor(const PdeAdiDesc* d, const float* ab, const float* bb, const float* as, const float* bs,
+                  float* coef, SweepTab* tab, int* varying, hipStream_t st) {
+    FactorArgs fa;
+    fill_factor_args(fa, d, ab, bb, as, bs);
+    fa.coef = coef; fa.tab = tab; fa.varying = varying;
+    const int total = d->num_sweeps * d->C * 32;
     hipLaunchKernelGGL(adi_factor_kernel, dim3((total + 63) / 64), dim3(64), 0, st, fa);
     return check_launch();
 }
@@ -777,13 +939,16 @@ std::vector<PendingEvent>& pending() {
     static std::vector<PendingEvent> v;
     return v;
 }
+std::mutex& launch_mutex() {
+    static std::mutex m;
+    return m;
+}
 
 template <typename K>
-int launch_sweep(K kernel, const SweepArgs& sa, int grid, size_t lds, hipStream_t st, bool is_fwd) {
-    static std::mutex mu;
+int launch_sweep(K kernel, const SweepArgs& sa, int grid, size_t lds, hipStream_t st, bool is_fwd, bool timed) {
     static std::vector<const void*> configured;
     {
-        std::lock_guard<std::mutex> lk(mu);
+        std::lock_guard<std::mutex> lk(launch_mutex());
         const void* key = reinterpret_cast<const void*>(kernel);
         bool seen = false;
         for (auto p : configured) seen |= (p == key);
@@ -796,38 +961,43 @@ int launch_sweep(K kernel, const SweepArgs& sa, int grid, size_t lds, hipStream_
     }
     Timing& tm = timing();
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (tm.on) {
+    const bool rec = tm.on && timed;
+    if (rec) {
         (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
         (void)hipEventRecord(e0, st);
     }
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), lds, st, sa);
     const int rc = check_launch();
-    if (tm.on) {
+    if (rec) {
         (void)hipEventRecord(e1, st);                     // resolved later, in pde_timing_read
-        std::lock_guard<std::mutex> lk(mu);
+        std::lock_guard<std::mutex> lk(launch_mutex());
         pending().push_back({e0, e1, is_fwd});
     }
     return rc;
 }
 
+#define PDE_N_LIST PDE_CASE(8) PDE_CASE(12) PDE_CASE(16) PDE_CASE(20) PDE_CASE(24) PDE_CASE(28) PDE_CASE(32)
+
 template <typename IO>
-int dispatch_fwd(int N, const SweepArgs& sa, int grid, size_t lds, hipStream_t st) {
+int dispatch_fwd(int N, const SweepArgs& sa, int grid, size_t lds, hipStream_t st, bool timed = true) {
     switch (N) {
-#define PDE_CASE(NN) case NN: return launch_sweep(adi_fwd_kernel<NN, kJFwd, IO>, sa, grid, lds, st, true);
-        PDE_CASE(8) PDE_CASE(12) PDE_CASE(16) PDE_CASE(20) PDE_CASE(24) PDE_CASE(28) PDE_CASE(32)
+#define PDE_CASE(NN) case NN: return launch_sweep(adi_fwd_kernel<NN, kJFwd, IO>, sa, grid, lds, st, true, timed);
+        PDE_N_LIST
 #undef PDE_CASE
     }
     return PDE_E_UNSUPPORTED_N;
 }
-template <typename IO>
+template <typename IO, bool MASKED>
 int dispatch_bwd(int N, const SweepArgs& sa, int grid, size_t lds, hipStream_t st) {
     switch (N) {
-#define PDE_CASE(NN) case NN: return launch_sweep(adi_bwd_kernel<NN, kJBwd, IO>, sa, grid, lds, st, false);
-        PDE_CASE(8) PDE_CASE(12) PDE_CASE(16) PDE_CASE(20) PDE_CASE(24) PDE_CASE(28) PDE_CASE(32)
+#define PDE_CASE(NN) case NN: return launch_sweep(adi_bwd_kernel<NN, kJBwd, IO, MASKED>, sa, grid, lds, st, false, !MASKED);
+        PDE_N_LIST
 #undef PDE_CASE
     }
     return PDE_E_UNSUPPORTED_N;
 }
+
+int count_ckpt(const uint64_t m[2]) { return m ? __builtin_popcountll(m[0]) + __builtin_popcountll(m[1]) : 0; }
 
 }  // namespace
 }  // namespace pde
@@ -842,12 +1012,11 @@ size_t pde_adi_forward_workspace_bytes(const PdeAdiDesc* d) {
 }
 
 size_t pde_adi_backward_workspace_bytes(const PdeAdiDesc* d, int32_t num_checkpoints) {
-    if (check_desc(d) != PDE_OK) return 0;
+    if (check_desc(d) != PDE_OK || num_checkpoints < 0) return 0;
     const int G = groups_per_channel(d, kWaves * kJBwd, 1);
-    size_t b = coef_bytes(d) + tab_bytes();
+    size_t b = coef_bytes(d) + tab_bytes() + flag_bytes(d);
     b += align_up((size_t)G * d->C * 4 * kImage * sizeof(float), 256);
-    b += 256;                                              // flags
-    (void)num_checkpoints;
+    b += align_up((size_t)num_checkpoints * d->B * d->C * d->N * d->N * sizeof(float), 256);
     return b;
 }
 
@@ -864,7 +1033,7 @@ int pde_adi_forward(const PdeAdiDesc* d, const void* u, void* y, const float* al
     rc = launch_factor(d, alpha_base, beta_base, alpha_slope, beta_slope, coef, tab, nullptr, st);
     if (rc != PDE_OK) return rc;
     SweepArgs sa{};
-    sa.in0 = u; sa.in1 = nullptr; sa.out = y; sa.coef = coef; sa.part = nullptr; sa.tab = tab;
+    sa.in0 = u; sa.out = y; sa.coef = coef; sa.tab = tab;
     sa.B = d->B; sa.C = d->C; sa.S = d->num_sweeps;
     sa.G = groups_per_channel(d, kWaves * kJFwd, 2);
     sa.one_eps = 1.0f + d->eps;
@@ -883,56 +1052,98 @@ int pde_adi_backward(const PdeAdiDesc* d, const void* gy, const void* y, const v
     if (!gy || !y || !gu || !alpha_base || !beta_base || !alpha_slope || !beta_slope || !g_alpha_base ||
         !g_beta_base || !g_alpha_slope || !g_beta_slope || !workspace)
         return PDE_E_BADARG;
-    if (ckpt_mask && (ckpt_mask[0] || ckpt_mask[1])) return PDE_E_BADARG;   // checkpoints: not implemented yet
-    (void)u;
-    if (workspace_bytes < pde_adi_backward_workspace_bytes(d, 0) || ((uintptr_t)workspace & 15)) return PDE_E_WORKSPACE;
+    const int nck = count_ckpt(ckpt_mask);
+    int Sf = 0;                                            // forward sweeps to recompute
+    if (nck) {
+        if (!u) return PDE_E_BADARG;
+        for (int s = 0; s < d->num_sweeps; ++s)
+            if ((ckpt_mask[s >> 6] >> (s & 63)) & 1ull) Sf = s + 1;
+        for (int s = d->num_sweeps; s < 128; ++s)
+            if ((ckpt_mask[s >> 6] >> (s & 63)) & 1ull) return PDE_E_BADARG;    // bit beyond the schedule
+        if (Sf >= d->num_sweeps) return PDE_E_BADARG;      // the last state is y itself
+    }
+    if (workspace_bytes < pde_adi_backward_workspace_bytes(d, nck) || ((uintptr_t)workspace & 15)) return PDE_E_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    char* ws = static_cast<char*>(workspace);
-    float* coef = reinterpret_cast<float*>(ws);
     const int G = groups_per_channel(d, kWaves * kJBwd, 1);
-    SweepTab* tab = reinterpret_cast<SweepTab*>(ws + coef_bytes(d));
-    float* part = reinterpret_cast<float*>(ws + coef_bytes(d) + tab_bytes());
-    int* flags = reinterpret_cast<int*>(ws + coef_bytes(d) + tab_bytes() +
-                                        align_up((size_t)G * d->C * 4 * kImage * sizeof(float), 256));
-    rc = launch_factor(d, alpha_base, beta_base, alpha_slope, beta_slope, coef, tab, nullptr, st);
+    char* ws = static_cast<char*>(workspace);
+    float* coef = reinterpret_cast<float*>(ws);           ws += coef_bytes(d);
+    SweepTab* tab = reinterpret_cast<SweepTab*>(ws);      ws += tab_bytes();
+    int* varying = reinterpret_cast<int*>(ws);            ws += flag_bytes(d);
+    float* part = reinterpret_cast<float*>(ws);           ws += align_up((size_t)G * d->C * 4 * kImage * sizeof(float), 256);
+    float* ckpt = reinterpret_cast<float*>(ws);
+    if (hipMemsetAsync(varying, 0, flag_bytes(d), st) != hipSuccess) return PDE_E_LAUNCH;
+    rc = launch_factor(d, alpha_base, beta_base, alpha_slope, beta_slope, coef, tab, varying, st);
     if (rc != PDE_OK) return rc;
-    if (hipMemsetAsync(flags, 0, 256, st) != hipSuccess) return PDE_E_LAUNCH;
 
     SweepArgs sa{};
-    sa.in0 = gy; sa.in1 = y; sa.out = gu; sa.coef = coef; sa.part = part; sa.tab = tab;
+    sa.in0 = gy; sa.in1 = y; sa.in2 = u; sa.out = gu; sa.coef = coef; sa.part = part; sa.tab = tab;
+    sa.varying = varying; sa.ckpt = ckpt;
+    sa.ck[0] = nck ? ckpt_mask[0] : 0ull; sa.ck[1] = nck ? ckpt_mask[1] : 0ull;
+    sa.Sf = Sf; sa.smooth3 = d->smooth3;
     sa.B = d->B; sa.C = d->C; sa.S = d->num_sweeps; sa.G = G;
     sa.one_eps = 1.0f + d->eps;
     float wgt[2] = {0.f, 0.f};
+    float tfirst[2] = {0.f, 0.f};
     bool have[2] = {false, false};
     for (int s = 0; s < d->num_sweeps; ++s) {
         const int ax = d->sweep[s].axis;
         const float w = d->sweep[s].delta / d->sweep[s].h2;
         if (have[ax] && w != wgt[ax]) return PDE_E_BADARG;   // one weight per axis (true for every reference variant)
+        if (!have[ax]) tfirst[ax] = d->sweep[s].t;
         wgt[ax] = w; have[ax] = true;
     }
-    const size_t lds = (size_t)(2 * kRecAll + kWaves * kImage) * sizeof(float);
+    if (nck) {
+        // pre-pass: run the forward from u up to the last checkpointed sweep and park those states
+        SweepArgs fa = sa;
+        fa.in0 = u; fa.in1 = nullptr; fa.out = nullptr; fa.part = nullptr;
+        fa.S = Sf;
+        fa.G = groups_per_channel(d, kWaves * kJFwd, 2);
+        const size_t lds_f = (size_t)(2 * kRecFwd + kWaves * kImage) * sizeof(float);
+        rc = d->io_dtype == PDE_IO_F32 ? dispatch_fwd<float>(d->N, fa, fa.G * d->C, lds_f, st, false)
+                                       : dispatch_fwd<bf16_t>(d->N, fa, fa.G * d->C, lds_f, st, false);
+        if (rc != PDE_OK) return rc;
+    }
     const int grid = G * d->C;
-    rc = d->io_dtype == PDE_IO_F32 ? dispatch_bwd<float>(d->N, sa, grid, lds, st)
-                                   : dispatch_bwd<bf16_t>(d->N, sa, grid, lds, st);
+    const size_t lds_fast = (size_t)(2 * kRecBwd + kWaves * kImage) * sizeof(float);
+    const size_t lds_mask = (size_t)(2 * kRecStride + kWaves * kImage) * sizeof(float);
+    // two launches over the same grid: every workgroup leaves at once unless its channel belongs
+    // to the instantiation (decided on the device by the factor kernel, no host round trip)
+    if (d->io_dtype == PDE_IO_F32) {
+        rc = dispatch_bwd<float, false>(d->N, sa, grid, lds_fast, st);
+        if (rc == PDE_OK) rc = dispatch_bwd<float, true>(d->N, sa, grid, lds_mask, st);
+    } else {
+        rc = dispatch_bwd<bf16_t, false>(d->N, sa, grid, lds_fast, st);
+        if (rc == PDE_OK) rc = dispatch_bwd<bf16_t, true>(d->N, sa, grid, lds_mask, st);
+    }
     if (rc != PDE_OK) return rc;
 
     PgradArgs pa{};
     pa.part = part; pa.ab = alpha_base; pa.bb = beta_base; pa.as = alpha_slope; pa.bs = beta_slope;
     pa.g_ab = g_alpha_base; pa.g_bb = g_beta_base; pa.g_as = g_alpha_slope; pa.g_bs = g_beta_slope;
-    pa.flags = flags;
+    pa.varying = varying;
     pa.C = d->C; pa.N = d->N; pa.S = d->num_sweeps; pa.G = G;
     pa.smooth3 = d->smooth3; pa.has_max = d->has_clamp_max; pa.accumulate = 0;
     pa.cmax = d->clamp_max; pa.eps = d->eps;
     pa.wx = wgt[0]; pa.wy = wgt[1];
-    for (int s = 0; s < d->num_sweeps; ++s) { pa.axis[s] = (unsigned char)d->sweep[s].axis; pa.t[s] = d->sweep[s].t; }
+    pa.t_first[0] = tfirst[0]; pa.t_first[1] = tfirst[1];
+    pa.have_axis[0] = have[0]; pa.have_axis[1] = have[1];
     hipLaunchKernelGGL(adi_pgrad_kernel, dim3(d->C), dim3(1024), 0, st, pa);
     return check_launch();
 }
 
 int pde_adi_kappa_max(const PdeAdiDesc* d, const float* alpha_base, const float* beta_base, const float* alpha_slope,
                       const float* beta_slope, float* kappa_max, void* stream) {
-    (void)d; (void)alpha_base; (void)beta_base; (void)alpha_slope; (void)beta_slope; (void)kappa_max; (void)stream;
-    return PDE_E_BADARG;   // filled in with the checkpoint planner
+    int rc = check_desc(d);
+    if (rc != PDE_OK) return rc;
+    if (!alpha_base || !beta_base || !alpha_slope || !beta_slope || !kappa_max) return PDE_E_BADARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(kappa_max, 0, (size_t)d->num_sweeps * sizeof(float), st) != hipSuccess) return PDE_E_LAUNCH;
+    FactorArgs fa;
+    fill_factor_args(fa, d, alpha_base, beta_base, alpha_slope, beta_slope);
+    fa.kmax = kappa_max;
+    const int total = d->num_sweeps * d->C * 32;
+    hipLaunchKernelGGL(adi_kmax_kernel, dim3((total + 63) / 64), dim3(64), 0, st, fa);
+    return check_launch();
 }
 
 int pde_timing_enable(int32_t on) {
@@ -957,6 +1168,6 @@ int pde_timing_read(double* fwd_ms_sum, int64_t* fwd_launches, double* bwd_ms_su
     return PDE_OK;
 }
 
-const char* pde_version(void) { return "pdecnn-hip 0.1 (gfx950)"; }
+const char* pde_version(void) { return "pdecnn-hip 0.2 (gfx950)"; }
 
 }  // extern "C"

@@ -17,14 +17,17 @@ constexpr int kImage = 32 * kLineStride;            // 1152 floats = 4608 B
 constexpr int kHalfPad = 16;
 
 // Coefficient record of one (sweep, channel), exactly as it sits in LDS:
-//   [JN 32][INV image][E image][KAPX image]
-// INV/E are indexed by the sweep's own lines; KAPX always by rows (x layout).
+//   [JN 32][INV image][E image][KAPX image][MASKX image]
+// INV/E are indexed by the sweep's own lines; KAPX (the coefficient itself) and MASKX (1 where
+// the clamp lets the gradient through, else 0) always by rows (x layout).
 constexpr int kRecJn = 0;
 constexpr int kRecInv = 32;
 constexpr int kRecE = 32 + kImage;
 constexpr int kRecKapX = 32 + 2 * kImage;
+constexpr int kRecMaskX = 32 + 3 * kImage;
 constexpr int kRecFwd = 32 + 2 * kImage;            // floats staged by the forward
-constexpr int kRecAll = 32 + 3 * kImage;            // floats staged by the backward
+constexpr int kRecBwd = 32 + 3 * kImage;            // floats staged by the backward (constant masks)
+constexpr int kRecStride = 32 + 4 * kImage;         // record stride in global memory; staged whole by the masked backward
 
 // position of global index j inside a line image row
 __host__ __device__ inline int half_pos(int j, int N) { return (j < N / 2) ? j : kHalfPad + (N - 1 - j); }

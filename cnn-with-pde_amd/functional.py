@@ -14,7 +14,7 @@ import torch
 
 from . import _lib as L
 
-__all__ = ["Sweep", "adi_schedule", "adi_diffuse", "channel_mix", "explicit5_step", "jacobi_diffuse",
+__all__ = ["Sweep", "adi_schedule", "adi_diffuse", "plan_checkpoints", "channel_mix", "explicit5_step", "jacobi_diffuse",
            "timing_enable", "timing_read"]
 
 
@@ -96,9 +96,30 @@ def _as_chw(p: torch.Tensor, Cc: int, N: int) -> torch.Tensor:
     return q.to(torch.float32).contiguous()
 
 
+#: amplification of rounding error tolerated when a state is rebuilt backwards from a later one
+#: (x_{s-1} = (A_s + eps I) x_s grows high-frequency error by up to 1 + 4*coeff per sweep)
+CKPT_AMAX = 8.0
+
+
+def plan_checkpoints(kappa_max: Sequence[float], amax: float = CKPT_AMAX) -> int:
+    """Bit s set: keep the state after sweep s as a checkpoint instead of rebuilding it.
+
+    Walking back from the output, the error amplification of the rebuilt state is the product of
+    (1 + 4*max coeff) over the sweeps undone since the last exact state; a checkpoint is placed
+    whenever that product would pass ``amax``.  Small coefficients (mnist, cifar: 1e-3) need none;
+    fashion-like ones (0.27 / 0.54) get one every two sweeps; very large ones one per sweep."""
+    mask, amp = 0, 1.0
+    for s in range(len(kappa_max) - 1, 0, -1):
+        amp *= 1.0 + 4.0 * float(kappa_max[s])
+        if amp > amax:
+            mask |= 1 << (s - 1)
+            amp = 1.0
+    return mask
+
+
 class _AdiFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, u, ab, bb, asl, bsl, sweeps, smooth3, clamp_max, eps):
+    def forward(ctx, u, ab, bb, asl, bsl, sweeps, smooth3, clamp_max, eps, ckpt):
         lib = L.load()
         _require_cuda(u, ab, bb, asl, bsl)
         if u.dim() != 4 or u.shape[2] != u.shape[3]:
@@ -115,41 +136,62 @@ class _AdiFn(torch.autograd.Function):
         with torch.cuda.device(u.device):
             L.check(lib.pde_adi_forward(C.byref(d), _ptr(u), _ptr(y), *[_ptr(t) for t in p],
                                         _ptr(ws), ws.numel(), _stream()), "pde_adi_forward")
-        ctx.save_for_backward(y, *p)
-        ctx.cfg = (sweeps, smooth3, clamp_max, eps)
+        ctx.kmax_host = ctx.kmax_event = None
+        need_grad = any(ctx.needs_input_grad[:5])
+        if need_grad and ckpt == "auto":
+            # per-sweep maximum coefficient, copied to the host asynchronously: the backward (which
+            # runs after the rest of the model) picks its checkpoints from it without a stall
+            kdev = torch.empty(len(sweeps), dtype=torch.float32, device=u.device)
+            with torch.cuda.device(u.device):
+                L.check(lib.pde_adi_kappa_max(C.byref(d), *[_ptr(t) for t in p], _ptr(kdev), _stream()),
+                        "pde_adi_kappa_max")
+                ctx.kmax_host = torch.empty(len(sweeps), dtype=torch.float32, pin_memory=True)
+                ctx.kmax_host.copy_(kdev, non_blocking=True)
+                ctx.kmax_event = torch.cuda.Event()
+                ctx.kmax_event.record()
+        ctx.save_for_backward(y, u if (need_grad and ckpt != 0) else None, *p)
+        ctx.cfg = (sweeps, smooth3, clamp_max, eps, ckpt)
         ctx.param_shapes = [t.shape for t in (ab, bb, asl, bsl)]
         return y
 
     @staticmethod
     def backward(ctx, gy):
         lib = L.load()
-        y, *p = ctx.saved_tensors
-        sweeps, smooth3, clamp_max, eps = ctx.cfg
+        y, u, *p = ctx.saved_tensors
+        sweeps, smooth3, clamp_max, eps, ckpt = ctx.cfg
         B, Cc, N, _ = y.shape
         gy = gy.to(y.dtype).contiguous()
         d = _make_desc(B, Cc, N, _io_dtype(y), sweeps, smooth3, clamp_max, eps)
         gu = torch.empty_like(y)
         gp = [torch.empty_like(t) for t in p]
-        mask = (C.c_uint64 * 2)(0, 0)
-        nbytes = lib.pde_adi_backward_workspace_bytes(C.byref(d), 0)
+        if ckpt == "auto":
+            ctx.kmax_event.synchronize()
+            bits = plan_checkpoints(ctx.kmax_host.tolist())
+        else:
+            bits = int(ckpt)
+        mask = (C.c_uint64 * 2)(bits & (2 ** 64 - 1), bits >> 64)
+        nbytes = lib.pde_adi_backward_workspace_bytes(C.byref(d), bin(bits).count("1"))
         ws = _workspace(nbytes, y.device)
         with torch.cuda.device(y.device):          # autograd thread: set device, fetch the stream here
-            L.check(lib.pde_adi_backward(C.byref(d), _ptr(gy), _ptr(y), _ptr(None), mask, _ptr(gu),
+            L.check(lib.pde_adi_backward(C.byref(d), _ptr(gy), _ptr(y), _ptr(u if bits else None), mask, _ptr(gu),
                                          *[_ptr(t) for t in p], *[_ptr(t) for t in gp],
                                          _ptr(ws), ws.numel(), _stream()), "pde_adi_backward")
         gp = [g.reshape(s) for g, s in zip(gp, ctx.param_shapes)]
-        return (gu, *gp, None, None, None, None)
+        return (gu, *gp, None, None, None, None, None)
 
 
 def adi_diffuse(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff, sweeps: Sequence[Sweep],
-                smooth3: bool = False, clamp_max: Optional[float] = None, eps: float = 1e-6):
+                smooth3: bool = False, clamp_max: Optional[float] = None, eps: float = 1e-6, checkpoints="auto"):
     """Run ``sweeps`` (a flat list) of implicit diffusion on ``u`` (B,C,N,N) in one fused launch.
 
     Replaces the reference's time loop over diffuse_x/diffuse_y/thomas_solver_batch
     (mnist_test.py:44-198, cifar10.py:74-211) and its autograd backward.
+
+    ``checkpoints``: "auto" (default) chooses the backward's checkpoints from the coefficients
+    (``plan_checkpoints``); an int is an explicit bit mask (0: rebuild every state from the output).
     """
     return _AdiFn.apply(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff, tuple(sweeps),
-                        bool(smooth3), clamp_max, float(eps))
+                        bool(smooth3), clamp_max, float(eps), checkpoints)
 
 
 # --------------------------------------------------------------------------- channel mixing
