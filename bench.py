@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Headline benchmark: forward+backward of the PDE diffusion layer (the hot path).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N = 1 runs in-process; for N > 1 the driver launches this file under torch.distributed.run
+(one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json configs[1]): cifar10.EnhancedDiffusionLayer
+(size 32, channels 64, dt 1e-3, 10 Strang steps = 30 implicit sweeps), batch 512 per GPU, fp32,
+synthetic N(0,1) input and upstream gradient, "trained-like" coefficients.  A step is one
+forward + backward of the layer over one batch; with N > 1 the batch is sharded (weak scaling)
+and the layer's parameter gradients are all-reduced over RCCL every step.
+Primary line: channel mixing disabled (diffusion path only — SURVEY.md §8d declares it the
+primary configuration; the C=64 mixing product is a GEMM outside the stencil path).  The
+same workload WITH channel mixing is reported under "secondary".
+"""
+import argparse
+import contextlib
+import io
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+BYTES_PER_ELEM = {"fwd": 8, "bwd": 12, "step": 20}   # fp32: u,y | gy,y,gu | total
+
+
+def build_layer(C, N, steps, dev, rank, mixing):
+    import cnn_with_pde_amd as P
+    with contextlib.redirect_stdout(io.StringIO()):
+        layer = P.EnhancedDiffusionLayer(N, C, dt=0.001, num_steps=steps, channel_mixing_enabled=mixing)
+    g = torch.Generator().manual_seed(99)       # same parameters on every rank
+    with torch.no_grad():                       # "trained-like" 
+        for n, p in layer.named_parameters():
+            if n in ("alpha_base", "beta_base"):
+                p.mul_(1 + 0.1 * torch.randn(p.shape, generator=g))
+            elif n in ("alpha_time_coeff", "beta_time_coeff"):
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+    return layer.to(dev)
+
+
+def run_steps(layer, u, gy, n, dist_on, flat):
+    for _ in range(n):
+        for p in layer.parameters():
+            p.grad = None
+        u.grad = None
+        y = layer(u)
+        y.backward(gy)
+        if dist_on:
+            import torch.distributed as dist
+            grads = [p.grad for p in layer.parameters() if p.grad is not None]
+            torch._foreach_copy_(list(flat.split([g.numel() for g in grads])), [g.reshape(-1) for g in grads])
+            dist.all_reduce(flat)               # one flat bucket (1.06 MB): latency-bound over xGMI
+            flat.div_(dist.get_world_size())
+
+
+def timed(layer, u, gy, steps, warmup, dist_on, flat):
+    import torch.distributed as dist
+    run_steps(layer, u, gy, warmup, dist_on, flat)
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(layer, u, gy, steps, dist_on, flat)
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist_on:
+        t = torch.tensor([dt], device=u.device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def cpu_baseline(C, N, steps, sample_B):
+    """The oracle in reference-faithful mode (per-unknown Python loop of torch ops, autograd
+    backward — what the reference does) on this box's host cores, bounded sample: a 2-sample
+    probe sizes the timed sample so that it stays near 20 s whatever the host is."""
+    from oracle import pde_oracle as O
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))             # the GPU box's CPU share for one GPU is 16
+    torch.set_num_threads(cores)
+    spec = O.AdiSpec(N, C, 0.001, 1.0, 1.0, steps, "strang", False, 10.0, "none", False)
+    g = torch.Generator().manual_seed(5)
+    params = O.adi_init_params(spec, "cifar10", gen=g)
+    params.pop("channel_mixing", None)
+
+    def once(nb):
+        u = torch.randn(nb, C, N, N, generator=g)
+        gy = torch.randn(nb, C, N, N, generator=g)
+        t0 = time.perf_counter()
+        O.value_and_grads(lambda a, p: O.adi_forward(a, p, spec), u, params, gy)
+        return time.perf_counter() - t0
+
+    print("[bench] cpu_baseline probe ...", file=sys.stderr, flush=True)
+    probe = once(2)
+    nb = int(max(2, min(sample_B, 2 * 20.0 / max(probe, 1e-3))))
+    print(f"[bench] cpu_baseline probe {probe:.1f} s for 2 samples; timing {nb} samples", file=sys.stderr, flush=True)
+    dt = once(nb)
+    return {"value": nb / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": f"B={nb} of the same (C={C},{N}x{N},{steps} steps) workload, one fwd+bwd, "
+                      f"oracle/pde_oracle.py in reference-faithful mode ({dt:.1f} s on {cores} threads)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=512, help="per-GPU batch")
+    ap.add_argument("--channels", type=int, default=64)
+    ap.add_argument("--size", type=int, default=32)
+    ap.add_argument("--num-steps", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=32)
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist_on = world > 1
+    if a.gpus != world and dist_on:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.gpus > 1 and not dist_on:
+        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nnodes=1 "
+                         "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if dist_on:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    import cnn_with_pde_amd as P
+    B, C, N, steps = a.batch, a.channels, a.size, a.num_steps
+    g = torch.Generator().manual_seed(1234 + rank)
+    u = torch.randn(B, C, N, N, generator=g).to(dev).requires_grad_(True)
+    gy = torch.randn(B, C, N, N, generator=g).to(dev)
+    layer = build_layer(C, N, steps, dev, rank, mixing=False)
+    nparam = sum(p.numel() for p in layer.parameters())
+    flat = torch.empty(nparam - layer.channel_mixing.numel(), device=dev) if dist_on else None
+
+    dt = timed(layer, u, gy, a.steps, a.warmup, dist_on, flat)
+    ms_step = dt / a.steps * 1e3
+    samples_s = B * world * a.steps / dt
+    elems = B * C * N * N
+
+    # per-kernel device time (HIP events on the launch stream, inside the library)
+    P.timing_enable(True)
+    run_steps(layer, u, gy, min(a.steps, 20), dist_on, flat)
+    f_ms, f_n, b_ms, b_n = P.timing_read()
+    P.timing_enable(False)
+    fwd_ms, bwd_ms = f_ms / max(f_n, 1), b_ms / max(b_n, 1)
+
+    out = None
+    if rank == 0:
+        pmc = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.isfile(pmc_path):
+            with open(pmc_path) as f:
+                pmc = json.load(f).get("adi_bwd_kernel_bytes_per_launch")
+        ach = elems * BYTES_PER_ELEM["bwd"] / (bwd_ms * 1e-3) / 1e9
+        out = {
+            "metric": "PDE-layer fwd+bwd Msamples/s", "value": samples_s / 1e6, "unit": "Msamples/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"cifar10.EnhancedDiffusionLayer(size={N}, channels={C}, num_steps={steps}) "
+                                   f"fwd+bwd, {3 * steps} implicit sweeps, batch {B}/GPU, channel mixing disabled "
+                                   "(BASELINE configs[1], SURVEY §8d cfg2 primary)",
+                       "global_batch": B * world, "parallelism": f"dp{world}",
+                       "grad_allreduce_bytes": (flat.numel() * 4 if flat is not None else 0)},
+            "roofline": {"bound": "hbm", "kernel": "adi_bwd_kernel", "achieved": ach, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc,
+                         "algorithmic_bytes_per_launch": elems * BYTES_PER_ELEM["bwd"], "avg_launch_ms": bwd_ms},
+            "roofline_fwd": {"bound": "hbm", "kernel": "adi_fwd_kernel",
+                             "achieved": elems * BYTES_PER_ELEM["fwd"] / (fwd_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "avg_launch_ms": fwd_ms},
+            "step_hbm": {"achieved": samples_s / world * C * N * N * BYTES_PER_ELEM["step"] / 1e9, "unit": "GB/s",
+                         "frac": samples_s / world * C * N * N * BYTES_PER_ELEM["step"] / 1e9 / HBM_PEAK_GBS,
+                         "note": "per GPU: samples/s x 20 B/element (whole step incl. launch gaps and small kernels)"},
+        }
+
+    if not a.no_secondary:
+        layer2 = build_layer(C, N, steps, dev, rank, mixing=True)
+        flat2 = torch.empty(nparam, device=dev) if dist_on else None
+        k2 = max(3, a.steps // 5)
+        dt2 = timed(layer2, u, gy, k2, 2, dist_on, flat2)
+        if rank == 0:
+            out["secondary"] = {"config": "same workload with the C x C channel mixing before every step "
+                                          "(cifar10.py:91), unfused: 10 x (mix kernel + 3-sweep ADI launch)",
+                                "value": B * world * k2 / dt2 / 1e6, "unit": "Msamples/s",
+                                "ms_per_step": dt2 / k2 * 1e3}
+        del layer2
+
+    if rank == 0:
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(C, N, steps, a.cpu_sample)
+        print(json.dumps(out))
+    if dist_on:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -14,7 +14,7 @@ import torch
 
 from . import _lib as L
 
-__all__ = ["Sweep", "adi_schedule", "adi_diffuse", "plan_checkpoints", "channel_mix", "explicit5_step", "jacobi_diffuse",
+__all__ = ["Sweep", "adi_schedule", "adi_diffuse", "plan_checkpoints", "kappa_max_async", "channel_mix", "explicit5_step", "jacobi_diffuse",
            "timing_enable", "timing_read"]
 
 
@@ -115,6 +115,24 @@ def plan_checkpoints(kappa_max: Sequence[float], amax: float = CKPT_AMAX) -> int
             mask |= 1 << (s - 1)
             amp = 1.0
     return mask
+
+
+def kappa_max_async(u_like, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff, sweeps: Sequence[Sweep],
+                    smooth3=False, clamp_max=None, eps=1e-6):
+    """Launch the per-sweep max-coefficient kernel and an asynchronous copy to pinned host memory.
+    Returns (host_tensor, event); the values are valid once ``event.query()`` is True."""
+    lib = L.load()
+    B, Cc, N, _ = u_like.shape
+    p = [_as_chw(t, Cc, N) for t in (alpha_base, beta_base, alpha_time_coeff, beta_time_coeff)]
+    d = _make_desc(B, Cc, N, L.PDE_IO_F32, sweeps, smooth3, clamp_max, eps)
+    kdev = torch.empty(len(sweeps), dtype=torch.float32, device=u_like.device)
+    with torch.cuda.device(u_like.device):
+        L.check(lib.pde_adi_kappa_max(C.byref(d), *[_ptr(t) for t in p], _ptr(kdev), _stream()), "pde_adi_kappa_max")
+        host = torch.empty(len(sweeps), dtype=torch.float32, pin_memory=True)
+        host.copy_(kdev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+    return host, ev
 
 
 class _AdiFn(torch.autograd.Function):

@@ -48,9 +48,34 @@ class _AdiBase(nn.Module):
         return (torch.clamp(alpha_t, min=self.stability_eps, max=self._clamp_max),
                 torch.clamp(beta_t, min=self.stability_eps, max=self._clamp_max))
 
+    #: "lagged" (default): the backward's checkpoints are chosen from the coefficients as they were
+    #: at the previous call (fetched asynchronously, no host stall; half the usual error budget to
+    #: cover one optimizer step of drift; the very first call waits once).  "auto": from the current
+    #: coefficients, at the price of one host wait per backward.  An int is an explicit bit mask.
+    checkpoint_policy = "lagged"
+
     def _diffuse(self, u, sweeps):
-        return F_.adi_diffuse(u, self.alpha_base, self.beta_base, self.alpha_time_coeff, self.beta_time_coeff,
-                              sweeps, smooth3=self._smooth3, clamp_max=self._clamp_max, eps=self.stability_eps)
+        args = (self.alpha_base, self.beta_base, self.alpha_time_coeff, self.beta_time_coeff)
+        kw = dict(smooth3=self._smooth3, clamp_max=self._clamp_max, eps=self.stability_eps)
+        ck = self.checkpoint_policy
+        if ck == "lagged":
+            if not (torch.is_grad_enabled() and (u.requires_grad or any(p.requires_grad for p in args))):
+                ck = 0
+            else:
+                cache = self.__dict__.setdefault("_kmax_cache", {})
+                key = (len(sweeps), sweeps[0].t, u.device)
+                fresh = F_.kappa_max_async(u, *args, sweeps, **kw)
+                old = cache.get(key)
+                if old is None:
+                    fresh[1].synchronize()                 # first call only
+                    bits = F_.plan_checkpoints(fresh[0].tolist(), F_.CKPT_AMAX / 2)
+                elif old[1].query():
+                    bits = F_.plan_checkpoints(old[0].tolist(), F_.CKPT_AMAX / 2)
+                else:
+                    bits = old[2]
+                cache[key] = (fresh[0], fresh[1], bits)
+                ck = bits
+        return F_.adi_diffuse(u, *args, sweeps, checkpoints=ck, **kw)
 
 
 class MnistDiffusionLayer(_AdiBase):
