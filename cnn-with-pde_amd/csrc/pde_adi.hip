@@ -71,152 +71,160 @@ struct FactorArgs {
 };
 
 __global__ __launch_bounds__(64) void adi_factor_kernel(FactorArgs a) {
-    const int idx = blockIdx.x * 64 + threadIdx.x;
+    // one wave = two records (sweep s, channels 2p and 2p+1); lane = (record, line).  Records are
+    // built in LDS and written out as whole 16-byte rows: a line-per-thread store straight to
+    // global memory is a 4-byte scatter and ran 10x slower.
+    __shared__ __attribute__((aligned(16))) float rec_s[2][kRecStride];
     const int N = a.N, m = N / 2;
-    if (idx < a.S) {                              // publish the sweep table
+    const int pairs = (a.C + 1) / 2;
+    const int s = blockIdx.x / pairs;
+    const int which = threadIdx.x >> 5;
+    const int c = 2 * (blockIdx.x % pairs) + which;
+    const int line = threadIdx.x & 31;
+    if (blockIdx.x == 0 && threadIdx.x < a.S) {   // publish the sweep table
+        const int idx = threadIdx.x;
         float tprev = 0.f, tlast = 0.f;
         int first = -1;
         const int ax = a.sweep[idx].axis;
-        for (int s = 0; s < a.S; ++s) {
-            if (a.sweep[s].axis != ax) continue;
-            if (first < 0) first = s;
-            if (s < idx) tprev = a.sweep[s].t;
-            tlast = a.sweep[s].t;
+        for (int q = 0; q < a.S; ++q) {
+            if (a.sweep[q].axis != ax) continue;
+            if (first < 0) first = q;
+            if (q < idx) tprev = a.sweep[q].t;
+            tlast = a.sweep[q].t;
         }
         a.tab->axis[idx] = ax;
         a.tab->dts[idx] = a.sweep[idx].t - tprev;
         a.tab->first_s[ax] = first;
         a.tab->t_last[ax] = tlast;
     }
-    const int line = idx % 32;
-    const int c = (idx / 32) % a.C;
-    const int s = idx / (32 * a.C);
-    if (s >= a.S) return;
-    if (line >= N) {
-        // lanes beyond the plane run the same instruction stream on zeros: give them finite
-        // (zero) coefficients so that nothing they compute can leak a NaN through a lane exchange
-        float* rec = a.coef + ((size_t)s * a.C + c) * kRecStride;
-        rec[kRecJn + line] = 0.f;
-        for (int i = 0; i < kLineStride; ++i) {
-            rec[kRecInv + line * kLineStride + i] = 0.f;
-            rec[kRecE + line * kLineStride + i] = 0.f;
-            rec[kRecKapX + line * kLineStride + i] = 0.f;
-            rec[kRecMaskX + line * kLineStride + i] = 0.f;
-        }
-        return;
-    }
+    float* rec = rec_s[which];
     const PdeSweep sw = a.sweep[s];
     const bool xax = sw.axis == PDE_AXIS_X;
-    const float* base = xax ? a.ab : a.bb;
-    const float* slope = xax ? a.as : a.bs;
-    const size_t cbase = (size_t)c * N * N;
-    const int st = xax ? 1 : N;                 // stride between consecutive unknowns of my line
-    const int o0 = xax ? line * N : line;
-
-    float kap[PDE_MAX_N];
-    float pass[PDE_MAX_N];
-    bool differs = false;
-    // theta = clamp(base + slope*t, eps[, max])          mnist_test.py:33-42
-    for (int i = 0; i < N; ++i) {
-        const float bs = base[cbase + o0 + i * st], sl = slope[cbase + o0 + i * st];
-        float th = bs + sl * sw.t;
-        const bool ps = (th >= a.eps) && (!a.has_max || th <= a.cmax);     // clamp passes the gradient
-        const float th0 = bs + sl * a.t_first[sw.axis];
-        const bool ps0 = (th0 >= a.eps) && (!a.has_max || th0 <= a.cmax);
-        differs |= (ps != ps0);
-        pass[i] = ps ? 1.0f : 0.0f;
-        th = fmaxf(th, a.eps);
-        if (a.has_max) th = fminf(th, a.cmax);
-        kap[i] = th;
+    const bool live = (c < a.C) && (line < N);
+    // idle lines get zero rows: lanes beyond the plane run the same instruction stream on zeros,
+    // so nothing they compute can leak a NaN through a lane exchange
+    rec[kRecJn + line] = 0.f;
+    for (int i = 0; i < kLineStride; ++i) {
+        rec[kRecInv + line * kLineStride + i] = 0.f;
+        rec[kRecE + line * kLineStride + i] = 0.f;
+        rec[kRecKapX + line * kLineStride + i] = 0.f;
+        rec[kRecMaskX + line * kLineStride + i] = 0.f;
     }
-    if (differs && a.varying) atomicOr(&a.varying[c], 1);
-    if (a.smooth3) {                             // mnist_test.py:135-149 (replicate ends)
-        const float third = 1.0f / 3.0f;
-        float prev = kap[0];
+    __syncthreads();
+    if (live) {
+        const float* base = xax ? a.ab : a.bb;
+        const float* slope = xax ? a.as : a.bs;
+        const size_t cbase = (size_t)c * N * N;
+        const int st = xax ? 1 : N;                 // stride between consecutive unknowns of my line
+        const int o0 = xax ? line * N : line;
+        float kap[PDE_MAX_N];
+        float pass[PDE_MAX_N];
+        bool differs = false;
+        // theta = clamp(base + slope*t, eps[, max])          mnist_test.py:33-42
         for (int i = 0; i < N; ++i) {
-            const float cur = kap[i];
-            const float nxt = kap[i + 1 < N ? i + 1 : N - 1];
-            kap[i] = (prev * third + cur * third) + nxt * third;
-            prev = cur;
+            const float bs = base[cbase + o0 + i * st], sl = slope[cbase + o0 + i * st];
+            float th = bs + sl * sw.t;
+            const bool ps = (th >= a.eps) && (!a.has_max || th <= a.cmax);     // clamp passes the gradient
+            const float th0 = bs + sl * a.t_first[sw.axis];
+            const bool ps0 = (th0 >= a.eps) && (!a.has_max || th0 <= a.cmax);
+            differs |= (ps != ps0);
+            pass[i] = ps ? 1.0f : 0.0f;
+            th = fmaxf(th, a.eps);
+            if (a.has_max) th = fminf(th, a.cmax);
+            kap[i] = th;
+        }
+        if (differs && a.varying) atomicOr(&a.varying[c], 1);
+        if (a.smooth3) {                             // mnist_test.py:135-149 (replicate ends)
+            const float third = 1.0f / 3.0f;
+            float prev = kap[0];
+            for (int i = 0; i < N; ++i) {
+                const float cur = kap[i];
+                const float nxt = kap[i + 1 < N ? i + 1 : N - 1];
+                kap[i] = (prev * third + cur * third) + nxt * third;
+                prev = cur;
+            }
+        }
+        for (int i = 0; i < N; ++i) kap[i] = (kap[i] * sw.delta) / sw.h2;     // coeff = theta*dt/dx**2  mnist_test.py:83
+        float* inv_row = rec + kRecInv + line * kLineStride;
+        float* e_row = rec + kRecE + line * kLineStride;
+        float e_in[2];
+        // two-sided elimination of (A + eps I): rows i = k (hf 0) and i = N-1-k (hf 1),
+        // den_k = b_k - kap_k * (kap_{k-1}/den_{k-1}) + eps       mnist_test.py:169,177
+        for (int hf = 0; hf < 2; ++hf) {
+            float e = 0.f;                           // kap_{k-1}/den_{k-1} of the outer neighbour
+            for (int k = 0; k < m; ++k) {
+                const int i = hf ? N - 1 - k : k;
+                const float kp = kap[i];
+                const float b = (k == 0) ? 1.0f + kp : 1.0f + 2.0f * kp;    // Neumann ends, mnist_test.py:88-93
+                const float den = (b - kp * e) + a.eps;
+                const float inv = 1.0f / den;
+                e = kp * inv;
+                inv_row[hf * kHalfPad + k] = inv;
+                e_row[hf * kHalfPad + k] = e;
+            }
+            e_in[hf] = e;
+        }
+        rec[kRecJn + line] = 1.0f / (1.0f - e_in[0] * e_in[1]);
+        // coefficient and clamp mask in row layout (always): element (h,w) at row h, half_pos(w)
+        float* kx = rec + kRecKapX;
+        float* mx = rec + kRecMaskX;
+        if (xax) {
+            for (int i = 0; i < N; ++i) {
+                kx[line * kLineStride + half_pos(i, N)] = kap[i];
+                mx[line * kLineStride + half_pos(i, N)] = pass[i];
+            }
+        } else {
+            const int p = half_pos(line, N);
+            for (int i = 0; i < N; ++i) {
+                kx[i * kLineStride + p] = kap[i];
+                mx[i * kLineStride + p] = pass[i];
+            }
         }
     }
-    float km = 0.f;
-    for (int i = 0; i < N; ++i) {                // coeff = theta*dt/dx**2   mnist_test.py:83
-        kap[i] = (kap[i] * sw.delta) / sw.h2;
-        km = fmaxf(km, kap[i]);
-    }
-
-    float* rec = a.coef + ((size_t)s * a.C + c) * kRecStride;
-    float* inv_row = rec + kRecInv + line * kLineStride;
-    float* e_row = rec + kRecE + line * kLineStride;
-    float e_in[2];
-    // two-sided elimination of (A + eps I): rows i = k (hf 0) and i = N-1-k (hf 1),
-    // den_k = b_k - kap_k * (kap_{k-1}/den_{k-1}) + eps       mnist_test.py:169,177
-    for (int hf = 0; hf < 2; ++hf) {
-        float cs_prev = 0.f;                     // kap_{k-1}/den_{k-1} of the outer neighbour
-        float e = 0.f;
-        for (int k = 0; k < m; ++k) {
-            const int i = hf ? N - 1 - k : k;
-            const float kp = kap[i];
-            const float b = (k == 0) ? 1.0f + kp : 1.0f + 2.0f * kp;    // Neumann ends, mnist_test.py:88-93
-            const float den = (b - kp * cs_prev) + a.eps;
-            const float inv = 1.0f / den;
-            cs_prev = kp / den;
-            e = kp * inv;
-            inv_row[hf * kHalfPad + k] = inv;
-            e_row[hf * kHalfPad + k] = e;
-        }
-        e_in[hf] = e;
-    }
-    rec[kRecJn + line] = 1.0f / (1.0f - e_in[0] * e_in[1]);
-    // kappa in row layout (always): element (h,w) at row h, half_pos(w)
-    float* kx = rec + kRecKapX;
-    float* mx = rec + kRecMaskX;
-    if (xax) {
-        for (int i = 0; i < N; ++i) {
-            kx[line * kLineStride + half_pos(i, N)] = kap[i];
-            mx[line * kLineStride + half_pos(i, N)] = pass[i];
-        }
-    } else {
-        const int p = half_pos(line, N);
-        for (int i = 0; i < N; ++i) {
-            kx[i * kLineStride + p] = kap[i];
-            mx[i * kLineStride + p] = pass[i];
-        }
+    __syncthreads();
+    for (int w = 0; w < 2; ++w) {
+        const int cw = 2 * (blockIdx.x % pairs) + w;
+        if (cw >= a.C) break;
+        float4* dst = reinterpret_cast<float4*>(a.coef + ((size_t)s * a.C + cw) * kRecStride);
+        const float4* src = reinterpret_cast<const float4*>(rec_s[w]);
+        for (int f = threadIdx.x; f < kRecStride / 4; f += 64) dst[f] = src[f];
     }
 }
 
 // max over the tensor of the coefficient of every sweep (no factorisation): feeds the host-side
-// choice of checkpoints.  One thread per (sweep, channel, line).
+// choice of checkpoints.  One wave per (sweep, pair of channels): lane = (channel of the pair, line);
+// the wave reduces its maximum and issues ONE atomic.
 __global__ __launch_bounds__(64) void adi_kmax_kernel(FactorArgs a) {
-    const int idx = blockIdx.x * 64 + threadIdx.x;
     const int N = a.N;
-    const int line = idx % 32;
-    const int c = (idx / 32) % a.C;
-    const int s = idx / (32 * a.C);
-    if (s >= a.S || line >= N) return;
-    const PdeSweep sw = a.sweep[s];
-    const bool xax = sw.axis == PDE_AXIS_X;
-    const float* base = xax ? a.ab : a.bb;
-    const float* slope = xax ? a.as : a.bs;
-    const size_t cbase = (size_t)c * N * N;
-    const int st = xax ? 1 : N;
-    const int o0 = xax ? line * N : line;
-    float th[PDE_MAX_N];
-    for (int i = 0; i < N; ++i) {
-        float v = base[cbase + o0 + i * st] + slope[cbase + o0 + i * st] * sw.t;
-        v = fmaxf(v, a.eps);
-        if (a.has_max) v = fminf(v, a.cmax);
-        th[i] = v;
-    }
+    const int pairs = (a.C + 1) / 2;
+    const int s = blockIdx.x / pairs;
+    const int c = 2 * (blockIdx.x % pairs) + (threadIdx.x >> 5);
+    const int line = threadIdx.x & 31;
     float km = 0.f;
-    const float third = 1.0f / 3.0f;
-    for (int i = 0; i < N; ++i) {
-        float v = th[i];
-        if (a.smooth3) v = (th[i > 0 ? i - 1 : 0] * third + th[i] * third) + th[i + 1 < N ? i + 1 : N - 1] * third;
-        km = fmaxf(km, (v * sw.delta) / sw.h2);
+    if (c < a.C && line < N) {
+        const PdeSweep sw = a.sweep[s];
+        const bool xax = sw.axis == PDE_AXIS_X;
+        const float* base = xax ? a.ab : a.bb;
+        const float* slope = xax ? a.as : a.bs;
+        const size_t cbase = (size_t)c * N * N;
+        const int st = xax ? 1 : N;
+        const int o0 = xax ? line * N : line;
+        float th[PDE_MAX_N];
+        for (int i = 0; i < N; ++i) {
+            float v = base[cbase + o0 + i * st] + slope[cbase + o0 + i * st] * sw.t;
+            v = fmaxf(v, a.eps);
+            if (a.has_max) v = fminf(v, a.cmax);
+            th[i] = v;
+        }
+        const float third = 1.0f / 3.0f;
+        for (int i = 0; i < N; ++i) {
+            float v = th[i];
+            if (a.smooth3) v = (th[i > 0 ? i - 1 : 0] * third + th[i] * third) + th[i + 1 < N ? i + 1 : N - 1] * third;
+            km = fmaxf(km, (v * sw.delta) / sw.h2);
+        }
     }
-    atomicMax((unsigned int*)&a.kmax[s], __float_as_uint(km));            // coefficients are > 0
+    for (int o = 32; o > 0; o >>= 1) km = fmaxf(km, __shfl_xor(km, o, 64));
+    if (threadIdx.x == 0) atomicMax((unsigned int*)&a.kmax[s], __float_as_uint(km));   // coefficients are > 0
 }
 
 // ------------------------------------------------------------------------------------
@@ -929,8 +937,7 @@ int launch_factor(const PdeAdiDesc* d, const float* ab, const float* bb, const f
     FactorArgs fa;
     fill_factor_args(fa, d, ab, bb, as, bs);
     fa.coef = coef; fa.tab = tab; fa.varying = varying;
-    const int total = d->num_sweeps * d->C * 32;
-    hipLaunchKernelGGL(adi_factor_kernel, dim3((total + 63) / 64), dim3(64), 0, st, fa);
+    hipLaunchKernelGGL(adi_factor_kernel, dim3(d->num_sweeps * ((d->C + 1) / 2)), dim3(64), 0, st, fa);
     return check_launch();
 }
 
@@ -1141,8 +1148,7 @@ int pde_adi_kappa_max(const PdeAdiDesc* d, const float* alpha_base, const float*
     FactorArgs fa;
     fill_factor_args(fa, d, alpha_base, beta_base, alpha_slope, beta_slope);
     fa.kmax = kappa_max;
-    const int total = d->num_sweeps * d->C * 32;
-    hipLaunchKernelGGL(adi_kmax_kernel, dim3((total + 63) / 64), dim3(64), 0, st, fa);
+    hipLaunchKernelGGL(adi_kmax_kernel, dim3(d->num_sweeps * ((d->C + 1) / 2)), dim3(64), 0, st, fa);
     return check_launch();
 }
 
