@@ -1,0 +1,628 @@
+// Device code of the K1 sweep kernels (included by pde_adi_inst.hip once per line length N,
+// and by pde_adi.hip for the argument structures).  See pde_adi.hip for the design notes.
+#pragma once
+#include "pde_common.h"
+
+#include <type_traits>
+
+namespace pde {
+namespace {
+
+constexpr int kWaves = 8;                         // waves per workgroup (512 threads)
+constexpr int kThreads = kWaves * 64;
+
+// Per-launch sweep table read by the sweep kernels with scalar loads (keeping it in the
+// kernel arguments makes hipcc hold all of it in SGPRs and spill them).
+struct SweepTab {
+    int axis[PDE_MAX_SWEEPS];
+    float dts[PDE_MAX_SWEEPS];      // bwd: t_s minus t of the previous (earlier) sweep of the same axis
+    int first_s[2];                 // bwd: earliest sweep of each axis (-1: none)
+    float t_last[2];                // bwd: time of the latest sweep of each axis
+};
+
+// order of the axes inside one time step, known at compile time for the two splits the
+// reference uses; kSplitAny looks the axis up per sweep
+constexpr int kSplitAny = 0;
+constexpr int kSplitStrang = 1;       // x, y, x   (mnist_test.py:55-63)
+constexpr int kSplitLie = 2;          // x, y      (cifar_2version.py:93-99)
+
+struct SweepArgs {
+    const void* in0;        // fwd: u        bwd: gy
+    const void* in1;        // fwd: -        bwd: y
+    void* out;              // fwd: y        bwd: gu
+    const float* coef;      // [S][C][kRecAll]
+    float* part;            // bwd: [G][C][4][kImage] partial parameter-gradient sums
+    const SweepTab* tab;
+    const int* varying;     // bwd: [C] per-channel "clamp mask changes with time" flag
+    const void* in2;        // bwd with checkpoints: u
+    float* ckpt;            // bwd with checkpoints: [slots][B][C][N][N] fp32
+    unsigned long long ck[2];   // bit s: the state after sweep s is checkpointed
+    int Sf;                 // bwd: sweeps 0..Sf-1 are recomputed forward first (0: no checkpoints)
+    int smooth3;
+    int B, C, S, G;
+    float one_eps;          // 1 + eps
+};
+
+__device__ __forceinline__ float xchg_half(float v) {     // value held by lane ^ 32
+    return __shfl_xor(v, 32, 64);
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+constexpr int kDppWaveShl1 = 0x130;   // lane i <- lane i+1
+constexpr int kDppWaveShr1 = 0x138;   // lane i <- lane i-1
+
+// Stage COUNT floats of a coefficient record global -> registers -> LDS: up to three 16-byte
+// pieces per thread, held in plain locals of the kernel (a struct here ends up in scratch).
+struct Staged { float4 r0, r1, r2; };
+template <int COUNT>
+__device__ __forceinline__ void stage_load(const float* src, int tid, float4& r0, float4& r1, float4& r2) {
+    constexpr int F4 = COUNT / 4;
+    static_assert(F4 <= 3 * kThreads, "record too large for three pieces per thread");
+    r0 = reinterpret_cast<const float4*>(src)[tid];
+    if constexpr (F4 > kThreads) {
+        if (F4 >= 2 * kThreads || tid + kThreads < F4) r1 = reinterpret_cast<const float4*>(src)[tid + kThreads];
+    }
+    if constexpr (F4 > 2 * kThreads) {
+        if (tid + 2 * kThreads < F4) r2 = reinterpret_cast<const float4*>(src)[tid + 2 * kThreads];
+    }
+}
+template <int COUNT>
+__device__ __forceinline__ void stage_store(float* dst, int tid, const float4& r0, const float4& r1, const float4& r2) {
+    constexpr int F4 = COUNT / 4;
+    reinterpret_cast<float4*>(dst)[tid] = r0;
+    if constexpr (F4 > kThreads) {
+        if (F4 >= 2 * kThreads || tid + kThreads < F4) reinterpret_cast<float4*>(dst)[tid + kThreads] = r1;
+    }
+    if constexpr (F4 > 2 * kThreads) {
+        if (tid + 2 * kThreads < F4) reinterpret_cast<float4*>(dst)[tid + 2 * kThreads] = r2;
+    }
+}
+
+// ---- plane I/O through the wave's LDS image (natural [h][w] rows, stride 36) --------
+template <typename IO> struct IoTraits;
+template <> struct IoTraits<float> {
+    static constexpr int kVec = 4;                      // elements per 16-byte access
+    __device__ static __forceinline__ float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+    __device__ static __forceinline__ void store4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+};
+struct bf16_t { unsigned short v; };
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned int)h << 16); }
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {      // round to nearest even, NaN kept
+    unsigned int u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+template <> struct IoTraits<bf16_t> {
+    __device__ static __forceinline__ float4 load4(const bf16_t* p) {
+        const ushort4 q = *reinterpret_cast<const ushort4*>(p);
+        return make_float4(bf16_to_f32(q.x), bf16_to_f32(q.y), bf16_to_f32(q.z), bf16_to_f32(q.w));
+    }
+    __device__ static __forceinline__ void store4(bf16_t* p, float4 v) {
+        ushort4 q;
+        q.x = f32_to_bf16(v.x); q.y = f32_to_bf16(v.y); q.z = f32_to_bf16(v.z); q.w = f32_to_bf16(v.w);
+        *reinterpret_cast<ushort4*>(p) = q;
+    }
+};
+
+template <int N>
+struct Geo {
+    static constexpr int M = N / 2;
+    static constexpr int NN4 = N * N / 4;               // float4 per plane
+    static constexpr int R4 = N / 4;                    // float4 per row
+    static constexpr int kLoads = (NN4 + 63) / 64;      // per-lane 16-byte accesses per plane
+};
+
+// global -> registers (issue only).  `valid` must be wave-uniform.
+template <int N, typename IO>
+__device__ __forceinline__ void plane_fetch(const IO* gp, bool valid, int lane, float4 (&q)[Geo<N>::kLoads]) {
+#pragma unroll
+    for (int i = 0; i < Geo<N>::kLoads; ++i) q[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) {
+#pragma unroll
+        for (int i = 0; i < Geo<N>::kLoads; ++i) {
+            const int f = i * 64 + lane;
+            if ((i + 1) * 64 <= Geo<N>::NN4 || f < Geo<N>::NN4) q[i] = IoTraits<IO>::load4(gp + 4 * f);
+        }
+    }
+}
+
+// compile-time loop: every index below is a constant in the AST, so register arrays are
+// scalarised before any select-of-loads folding can turn them into dynamic indexing
+template <int I, int E, class F>
+__device__ __forceinline__ void sfor(F&& f) {
+    if constexpr (I < E) {
+        f(std::integral_constant<int, I>{});
+        sfor<I + 1, E>(f);
+    }
+}
+
+// Plane I/O goes through a wave-private LDS image whose rows are in natural order and whose
+// columns are in half order (half_pos): the coalesced side (float4 = two pairs of columns)
+// puts each pair where its half expects it, swapping the two floats of a pair that lands in
+// the mirrored high half; the row side then moves whole half rows with ds_*_b128.
+template <int N>
+__device__ __forceinline__ int pair_slot(int row, int w, bool& swapped) {
+    swapped = w >= N / 2;                       // w is even and N/2 is even-or-odd*2: pairs never straddle
+    return row * kLineStride + (swapped ? kHalfPad + (N - 2 - w) : w);
+}
+
+template <int N>
+__device__ __forceinline__ void plane_to_rows(const float4 (&q)[Geo<N>::kLoads], float* T, int lane, int l, int hf,
+                                              float (&v)[Geo<N>::M]) {
+    constexpr int M = Geo<N>::M;
+#pragma unroll
+    for (int i = 0; i < Geo<N>::kLoads; ++i) {
+        const int f = i * 64 + lane;
+        if ((i + 1) * 64 <= Geo<N>::NN4 || f < Geo<N>::NN4) {
+            const int row = f / Geo<N>::R4, w0 = 4 * (f % Geo<N>::R4);
+            bool s0, s1;
+            const int a0 = pair_slot<N>(row, w0, s0), a1 = pair_slot<N>(row, w0 + 2, s1);
+            *reinterpret_cast<float2*>(&T[a0]) = s0 ? make_float2(q[i].y, q[i].x) : make_float2(q[i].x, q[i].y);
+            *reinterpret_cast<float2*>(&T[a1]) = s1 ? make_float2(q[i].w, q[i].z) : make_float2(q[i].z, q[i].w);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const float* src = T + l * kLineStride + hf * kHalfPad;
+#pragma unroll
+    for (int i = 0; i < (M + 3) / 4; ++i) {
+        const float4 x = *reinterpret_cast<const float4*>(src + 4 * i);
+        v[4 * i] = x.x;
+        if (4 * i + 1 < M) v[4 * i + 1] = x.y;
+        if (4 * i + 2 < M) v[4 * i + 2] = x.z;
+        if (4 * i + 3 < M) v[4 * i + 3] = x.w;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int N, typename IO>
+__device__ __forceinline__ void rows_to_plane(const float (&v)[Geo<N>::M], float* T, int lane, int l, int hf,
+                                              IO* gp, bool valid) {
+    constexpr int M = Geo<N>::M;
+    if (l < N) {
+        float* dst = T + l * kLineStride + hf * kHalfPad;
+#pragma unroll
+        for (int i = 0; i < (M + 3) / 4; ++i) {
+            float4 x;
+            x.x = v[4 * i];
+            x.y = (4 * i + 1 < M) ? v[4 * i + 1] : 0.f;
+            x.z = (4 * i + 2 < M) ? v[4 * i + 2] : 0.f;
+            x.w = (4 * i + 3 < M) ? v[4 * i + 3] : 0.f;
+            *reinterpret_cast<float4*>(dst + 4 * i) = x;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < Geo<N>::kLoads; ++i) {
+        const int f = i * 64 + lane;
+        if ((i + 1) * 64 <= Geo<N>::NN4 || f < Geo<N>::NN4) {
+            const int row = f / Geo<N>::R4, w0 = 4 * (f % Geo<N>::R4);
+            bool s0, s1;
+            const int a0 = pair_slot<N>(row, w0, s0), a1 = pair_slot<N>(row, w0 + 2, s1);
+            const float2 p0 = *reinterpret_cast<const float2*>(&T[a0]);
+            const float2 p1 = *reinterpret_cast<const float2*>(&T[a1]);
+            float4 x;
+            x.x = s0 ? p0.y : p0.x; x.y = s0 ? p0.x : p0.y;
+            x.z = s1 ? p1.y : p1.x; x.w = s1 ? p1.x : p1.y;
+            if (valid) IoTraits<IO>::store4(gp + 4 * f, x);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// row layout <-> column layout of one plane (an involution; same code both ways).
+// The image used here is private to this exchange, so its rows and its columns are both kept
+// in half order (row index hf*M + k, column index half_pos): every access is then
+// lane base + compile-time offset.
+template <int N>
+__device__ __forceinline__ void relayout(float (&v)[Geo<N>::M], float* T, int l, int hf) {
+    constexpr int M = Geo<N>::M;
+    if (l < N) {
+        const int mypos = (l < M) ? l : kHalfPad + (N - 1 - l);
+        float* dst = T + hf * M * kLineStride + mypos;
+#pragma unroll
+        for (int k = 0; k < M; ++k) dst[k * kLineStride] = v[k];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int myrow = (l < M) ? l : M + (N - 1 - l);
+    const float* src = T + myrow * kLineStride + hf * kHalfPad;
+#pragma unroll
+    for (int i = 0; i < (M + 3) / 4; ++i) {
+        const float4 x = *reinterpret_cast<const float4*>(src + 4 * i);
+        v[4 * i] = x.x;
+        if (4 * i + 1 < M) v[4 * i + 1] = x.y;
+        if (4 * i + 2 < M) v[4 * i + 2] = x.z;
+        if (4 * i + 3 < M) v[4 * i + 3] = x.w;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int M>
+__device__ __forceinline__ void load_half(const float* src, float (&dst)[M]) {
+#pragma unroll
+    for (int i = 0; i < (M + 3) / 4; ++i) {
+        const float4 x = *reinterpret_cast<const float4*>(src + 4 * i);
+        dst[4 * i] = x.x;
+        if (4 * i + 1 < M) dst[4 * i + 1] = x.y;
+        if (4 * i + 2 < M) dst[4 * i + 2] = x.z;
+        if (4 * i + 3 < M) dst[4 * i + 3] = x.w;
+    }
+}
+
+// ---- forward: (A + eps I) x = d on J planes, two-sided ---------------------------------
+template <int M, int J>
+__device__ __forceinline__ void solve_fwd(float (&v)[J][M], const float* rec, int l, int hf) {
+    float e[M], inv[M];
+    load_half<M>(rec + kRecE + l * kLineStride + hf * kHalfPad, e);
+    load_half<M>(rec + kRecInv + l * kLineStride + hf * kHalfPad, inv);
+    const float jn = rec[kRecJn + l];
+    // elimination from my end inwards: D_k = d_k*inv_k + e_k*D_{k-1}
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const float t = v[j][k] * inv[k];
+            v[j][k] = (k == 0) ? t : fmaf(e[k], v[j][k - 1], t);
+        }
+    }
+    // junction: x_in = (D_in + e_in * D_in(partner)) / (1 - e_t e_b)
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const float other = xchg_half(v[j][M - 1]);
+        v[j][M - 1] = fmaf(e[M - 1], other, v[j][M - 1]) * jn;
+    }
+    // substitution outwards: x_k = D_k + e_k*x_{k+1}
+#pragma unroll
+    for (int k = M - 2; k >= 0; --k) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) v[j][k] = fmaf(e[k], v[j][k + 1], v[j][k]);
+    }
+}
+
+__device__ __forceinline__ int ck_slot(const unsigned long long (&ck)[2], int s) {
+    return s < 64 ? __builtin_popcountll(ck[0] & ((1ull << s) - 1ull))
+                  : __builtin_popcountll(ck[0]) + __builtin_popcountll(ck[1] & ((1ull << (s - 64)) - 1ull));
+}
+__device__ __forceinline__ int ck_bit(const unsigned long long (&ck)[2], int s) {
+    return (int)((ck[s >> 6] >> (s & 63)) & 1ull);
+}
+
+template <int N, int J, typename IO>
+__device__ __forceinline__ void load_planes(const IO* base, int q, int wave, int lane, int l, int hf, int B, int C,
+                                            int c, float* T, float (&v)[J][N / 2]) {
+    constexpr int PPI = kWaves * J;
+    float4 raw[J][Geo<N>::kLoads];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int b = q * PPI + wave * J + j;
+        plane_fetch<N, IO>(base + ((size_t)b * C + c) * (size_t)(N * N), b < B, lane, raw[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) plane_to_rows<N>(raw[j], T, lane, l, hf, v[j]);
+}
+
+template <int N, int J, typename IO>
+__device__ __forceinline__ void store_planes(IO* base, int q, int wave, int lane, int l, int hf, int B, int C, int c,
+                                             float* T, const float (&v)[J][N / 2]) {
+    constexpr int PPI = kWaves * J;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int b = q * PPI + wave * J + j;
+        rows_to_plane<N, IO>(v[j], T, lane, l, hf, base + ((size_t)b * C + c) * (size_t)(N * N), b < B);
+    }
+}
+
+// ---- forward kernel ---------------------------------------------------------------------
+// SPLIT fixes the order of the axes inside a time step at compile time (straight-line code per
+// step, no per-sweep axis branch); kSplitAny reads the axis of every sweep from the table.
+template <int N, int J, typename IO, int SPLIT>
+__global__ __launch_bounds__(kThreads) void adi_fwd_kernel(SweepArgs a) {
+    constexpr int M = Geo<N>::M;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* cbuf = smem;                                   // [2][kRecFwd]
+    float* tbuf = smem + 2 * kRecFwd;                     // [kWaves][kImage]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hf = lane >> 5, l = lane & 31;
+    const int c = blockIdx.x % a.C, g = blockIdx.x / a.C;
+    float* T = tbuf + wave * kImage;
+    const IO* u = static_cast<const IO*>(a.in0);
+    IO* y = static_cast<IO*>(a.out);
+    constexpr int PPI = kWaves * J;                       // planes per workgroup iteration
+    const int nchunk = (a.B + PPI - 1) / PPI;
+    const size_t plane = (size_t)N * N;
+
+    // rows >= N of the wave images are never written: zero them once so idle lanes read zeros
+    for (int e = tid; e < kWaves * kImage; e += kThreads) tbuf[e] = 0.f;
+    float4 st0 = make_float4(0.f, 0.f, 0.f, 0.f), st1 = st0, st2 = st0;
+    unsigned n = 0;                                       // running sweep counter (buffer parity)
+    stage_load<kRecFwd>(a.coef + ((size_t)0 * a.C + c) * kRecStride, tid, st0, st1, st2);
+    stage_store<kRecFwd>(cbuf, tid, st0, st1, st2);
+    __syncthreads();
+
+    for (int q = g; q < nchunk; q += a.G) {
+        float v[J][M];
+        load_planes<N, J, IO>(u, q, wave, lane, l, hf, a.B, a.C, c, T, v);
+        const bool more = q + a.G < nchunk;
+        auto sweep = [&](auto AXC, int s) {
+            constexpr int AX = decltype(AXC)::value;
+            const int snext = (s + 1 < a.S) ? s + 1 : 0;
+            const bool pre = (s + 1 < a.S) || more;
+            if (pre) stage_load<kRecFwd>(a.coef + ((size_t)snext * a.C + c) * kRecStride, tid, st0, st1, st2);
+            const float* rec = cbuf + (n & 1) * kRecFwd;
+            const int axs = (AX >= 0) ? AX : a.tab->axis[s];
+            if (axs == PDE_AXIS_Y) {
+#pragma unroll
+                for (int j = 0; j < J; ++j) relayout<N>(v[j], T, l, hf);
+            }
+            solve_fwd<M, J>(v, rec, l, hf);
+            if (axs == PDE_AXIS_Y) {
+#pragma unroll
+                for (int j = 0; j < J; ++j) relayout<N>(v[j], T, l, hf);
+            }
+            if (a.ckpt != nullptr && ck_bit(a.ck, s)) {   // backward pre-pass: park this state (fp32)
+                float* slot = a.ckpt + (size_t)ck_slot(a.ck, s) * a.B * a.C * plane;
+                store_planes<N, J, float>(slot, q, wave, lane, l, hf, a.B, a.C, c, T, v);
+            }
+            if (pre) stage_store<kRecFwd>(cbuf + ((n + 1) & 1) * kRecFwd, tid, st0, st1, st2);
+            __syncthreads();
+            ++n;
+        };
+        if constexpr (SPLIT == kSplitStrang) {
+            for (int s = 0; s < a.S; s += 3) {
+                sweep(std::integral_constant<int, PDE_AXIS_X>{}, s);
+                sweep(std::integral_constant<int, PDE_AXIS_Y>{}, s + 1);
+                sweep(std::integral_constant<int, PDE_AXIS_X>{}, s + 2);
+            }
+        } else if constexpr (SPLIT == kSplitLie) {
+            for (int s = 0; s < a.S; s += 2) {
+                sweep(std::integral_constant<int, PDE_AXIS_X>{}, s);
+                sweep(std::integral_constant<int, PDE_AXIS_Y>{}, s + 1);
+            }
+        } else {
+            for (int s = 0; s < a.S; ++s) sweep(std::integral_constant<int, -1>{}, s);
+        }
+        if (y != nullptr) store_planes<N, J, IO>(y, q, wave, lane, l, hf, a.B, a.C, c, T, v);
+    }
+}
+
+// ---- backward -------------------------------------------------------------------------
+// adjoint two-sided solve (A + eps I)^T g = r on J planes, in place.
+template <int M, int J>
+__device__ __forceinline__ void solve_adj(float (&r)[J][M], const float* rec, int l, int hf) {
+    __builtin_amdgcn_sched_barrier(0);
+    float e[M];
+    load_half<M>(rec + kRecE + l * kLineStride + hf * kHalfPad, e);
+    const float jn = rec[kRecJn + l];
+    // H_k = r_k + e_{k-1} H_{k-1}
+#pragma unroll
+    for (int k = 1; k < M; ++k) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) r[j][k] = fmaf(e[k - 1], r[j][k - 1], r[j][k]);
+    }
+    // junction: G_in = (H_in + e_in(partner) H_in(partner)) / (1 - e_t e_b)
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const float pv = xchg_half(e[M - 1] * r[j][M - 1]);
+        r[j][M - 1] = (r[j][M - 1] + pv) * jn;
+    }
+    // G_k = H_k + e_{k+1} G_{k+1};   g_k = inv_k G_k
+#pragma unroll
+    for (int k = M - 2; k >= 0; --k) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) r[j][k] = fmaf(e[k + 1], r[j][k + 1], r[j][k]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float inv[M];
+    load_half<M>(rec + kRecInv + l * kLineStride + hf * kHalfPad, inv);
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) r[j][k] *= inv[k];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// After an x sweep has been undone on the adjoint (g in r[]), use the sweep's OUTPUT state
+// x to (1) add g.(Lx) to the coefficient-gradient sums, (2) rebuild the sweep's input
+// x_prev = (1+eps) x + kap.(Lx).  L = Neumann second difference along the row.
+// MASKED: the clamp mask of this channel changes with time, so the sum over sweeps cannot be
+// masked (and un-smoothed) once at the end: do both here, per sweep.
+template <int M, int J, bool MASKED>
+__device__ __forceinline__ void state_x(const float (&g)[J][M], float (&x)[J][M], float (&acc)[M],
+                                        const float* rec, int l, int hf, float one_eps, int smooth) {
+    float kap[M];
+    load_half<M>(rec + kRecKapX + l * kLineStride + hf * kHalfPad, kap);
+    float msk[MASKED ? M : 1];
+    if constexpr (MASKED) load_half<M>(rec + kRecMaskX + l * kLineStride + hf * kHalfPad, msk);
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        float gq[MASKED ? M : 1];
+        float xo_next = xchg_half(x[j][M - 1]);          // inner neighbour of k = M-1
+#pragma unroll
+        for (int k = M - 1; k >= 0; --k) {
+            const float xo = x[j][k];
+            float q = (k == 0) ? xo - xo_next : fmaf(2.0f, xo, -x[j][k - 1]) - xo_next;
+            if constexpr (MASKED) gq[k] = g[j][k] * q;
+            else acc[k] = fmaf(g[j][k], q, acc[k]);
+            x[j][k] = fmaf(kap[k], q, xo * one_eps);
+            xo_next = xo;
+        }
+        if constexpr (MASKED) {
+            if (smooth) {                                // transpose of the replicate 3-tap average (x1/3 later)
+                const float gin = xchg_half(gq[M - 1]);
+#pragma unroll
+                for (int k = 0; k < M; ++k) {
+                    float z = (k == 0) ? 2.0f * gq[0] : gq[k] + gq[k - 1];
+                    z += (k < M - 1) ? gq[k + 1] : gin;
+                    acc[k] = fmaf(msk[k], z, acc[k]);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < M; ++k) acc[k] = fmaf(msk[k], gq[k], acc[k]);
+            }
+        }
+    }
+}
+
+// Same for a y sweep, with the state (and g) in ROW layout: the second difference (and, when
+// MASKED, the transposed smoothing) runs across lanes (rows h-1, h+1 = lanes l-1, l+1 of the
+// same half).
+template <int N, int J, bool MASKED>
+__device__ __forceinline__ void state_y(const float (&g)[J][N / 2], float (&x)[J][N / 2], float (&acc)[N / 2],
+                                        const float* rec, int l, int hf, float one_eps, int smooth) {
+    constexpr int M = N / 2;
+    float kap[M];
+    load_half<M>(rec + kRecKapX + l * kLineStride + hf * kHalfPad, kap);
+    float msk[MASKED ? M : 1];
+    if constexpr (MASKED) load_half<M>(rec + kRecMaskX + l * kLineStride + hf * kHalfPad, msk);
+    const bool edge = (l == 0 || l == N - 1);
+    const float kk = edge ? 1.0f : 2.0f;
+    const float kz = edge ? 2.0f : 1.0f;
+    const float mu = (l > 0) ? 1.0f : 0.0f;
+    const float md = (l < N - 1) ? 1.0f : 0.0f;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+#pragma unroll
+        for (int k = 0; k < M; ++k) {
+            const float xo = x[j][k];
+            const float up = dpp_move<kDppWaveShr1>(xo);
+            const float dn = dpp_move<kDppWaveShl1>(xo);
+            float q = kk * xo;
+            q = fmaf(-mu, up, q);
+            q = fmaf(-md, dn, q);
+            if constexpr (MASKED) {
+                const float gq = g[j][k] * q;
+                float z = gq;
+                if (smooth) {
+                    const float zu = dpp_move<kDppWaveShr1>(gq);
+                    const float zd = dpp_move<kDppWaveShl1>(gq);
+                    z = kz * gq;
+                    z = fmaf(mu, zu, z);
+                    z = fmaf(md, zd, z);
+                }
+                acc[k] = fmaf(msk[k], z, acc[k]);
+            } else {
+                acc[k] = fmaf(g[j][k], q, acc[k]);
+            }
+            x[j][k] = fmaf(kap[k], q, xo * one_eps);
+        }
+    }
+}
+
+template <int N, int J, typename IO, bool MASKED, int SPLIT>
+__global__ __launch_bounds__(kThreads) void adi_bwd_kernel(SweepArgs a) {
+    constexpr int M = Geo<N>::M;
+    constexpr int REC = MASKED ? kRecStride : kRecBwd;
+    const int c = blockIdx.x % a.C, g = blockIdx.x / a.C;
+    if ((a.varying[c] != 0) != MASKED) return;            // the other instantiation owns this channel
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* cbuf = smem;                                   // [2][REC]
+    float* tbuf = smem + 2 * REC;                         // [kWaves][kImage]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hf = lane >> 5, l = lane & 31;
+    float* T = tbuf + wave * kImage;
+    const IO* gy = static_cast<const IO*>(a.in0);
+    const IO* yy = static_cast<const IO*>(a.in1);
+    IO* gu = static_cast<IO*>(a.out);
+    constexpr int PPI = kWaves * J;
+    const int nchunk = (a.B + PPI - 1) / PPI;
+    const size_t plane = (size_t)N * N;
+
+    float Ax[M], Tx[M], Ay[M], Ty[M];
+#pragma unroll
+    for (int k = 0; k < M; ++k) Ax[k] = Tx[k] = Ay[k] = Ty[k] = 0.f;
+
+    for (int e = tid; e < kWaves * kImage; e += kThreads) tbuf[e] = 0.f;
+    float4 st0 = make_float4(0.f, 0.f, 0.f, 0.f), st1 = st0, st2 = st0;
+    unsigned n = 0;
+    stage_load<REC>(a.coef + ((size_t)(a.S - 1) * a.C + c) * kRecStride, tid, st0, st1, st2);
+    stage_store<REC>(cbuf, tid, st0, st1, st2);
+    __syncthreads();
+
+    for (int q = g; q < nchunk; q += a.G) {
+        float r[J][M], x[J][M];
+        load_planes<N, J, IO>(gy, q, wave, lane, l, hf, a.B, a.C, c, T, r);
+        load_planes<N, J, IO>(yy, q, wave, lane, l, hf, a.B, a.C, c, T, x);
+        // The time-weighted sums use summation by parts over the whole processing sequence
+        // (all chunks, sweeps in decreasing time):  sum_i tau_i G_i = sum_i (tau_i - tau_{i+1}) R_i
+        // with R_i the running sum of g.q and tau_{i+1} the time of the next processed sweep of
+        // the same axis (0 after the very last one).  So Ax/Ay double as R and are never reset.
+        const bool more = q + a.G < nchunk;
+        auto sweep = [&](auto AXC, int s) {
+            constexpr int AX = decltype(AXC)::value;
+            const int snext = (s > 0) ? s - 1 : a.S - 1;
+            const bool pre = (s > 0) || more;
+            if (pre) stage_load<REC>(a.coef + ((size_t)snext * a.C + c) * kRecStride, tid, st0, st1, st2);
+            const float* rec = cbuf + (n & 1) * REC;
+            const int axs = (AX >= 0) ? AX : a.tab->axis[s];
+            float dts = a.tab->dts[s];
+            if (more && s == a.tab->first_s[axs]) dts -= a.tab->t_last[axs];
+            if (axs == PDE_AXIS_Y) {
+#pragma unroll
+                for (int j = 0; j < J; ++j) relayout<N>(r[j], T, l, hf);
+                solve_adj<M, J>(r, rec, l, hf);
+#pragma unroll
+                for (int j = 0; j < J; ++j) relayout<N>(r[j], T, l, hf);
+                state_y<N, J, MASKED>(r, x, Ay, rec, l, hf, a.one_eps, a.smooth3);
+                if (dts != 0.f) {
+#pragma unroll
+                    for (int k = 0; k < M; ++k) Ty[k] = fmaf(dts, Ay[k], Ty[k]);
+                }
+            } else {
+                solve_adj<M, J>(r, rec, l, hf);
+                state_x<M, J, MASKED>(r, x, Ax, rec, l, hf, a.one_eps, a.smooth3);
+                if (dts != 0.f) {
+#pragma unroll
+                    for (int k = 0; k < M; ++k) Tx[k] = fmaf(dts, Ax[k], Tx[k]);
+                }
+            }
+            // x now holds the rebuilt state after sweep s-1; take the checkpoint instead if there is one
+            if (s > 0 && a.ckpt != nullptr && ck_bit(a.ck, s - 1)) {
+                const float* slot = a.ckpt + (size_t)ck_slot(a.ck, s - 1) * a.B * a.C * plane;
+                load_planes<N, J, float>(slot, q, wave, lane, l, hf, a.B, a.C, c, T, x);
+            }
+            if (pre) stage_store<REC>(cbuf + ((n + 1) & 1) * REC, tid, st0, st1, st2);
+            __syncthreads();
+            ++n;
+        };
+        if constexpr (SPLIT == kSplitStrang) {
+            for (int s = a.S - 1; s >= 0; s -= 3) {
+                sweep(std::integral_constant<int, PDE_AXIS_X>{}, s);
+                sweep(std::integral_constant<int, PDE_AXIS_Y>{}, s - 1);
+                sweep(std::integral_constant<int, PDE_AXIS_X>{}, s - 2);
+            }
+        } else if constexpr (SPLIT == kSplitLie) {
+            for (int s = a.S - 1; s >= 0; s -= 2) {
+                sweep(std::integral_constant<int, PDE_AXIS_Y>{}, s);
+                sweep(std::integral_constant<int, PDE_AXIS_X>{}, s - 1);
+            }
+        } else {
+            for (int s = a.S - 1; s >= 0; --s) sweep(std::integral_constant<int, -1>{}, s);
+        }
+        store_planes<N, J, IO>(gu, q, wave, lane, l, hf, a.B, a.C, c, T, r);
+    }
+
+    // deterministic reduction of the four sums over the waves of this workgroup
+    __syncthreads();
+    float* dst = a.part + ((size_t)g * a.C + c) * 4 * kImage;
+#pragma unroll
+    for (int arr = 0; arr < 4; ++arr) {
+        float* row = T + l * kLineStride + hf * kHalfPad;
+#pragma unroll
+        for (int k = 0; k < M; ++k) row[k] = (arr == 0) ? Ax[k] : (arr == 1) ? Tx[k] : (arr == 2) ? Ay[k] : Ty[k];
+        __syncthreads();
+        for (int e = tid; e < kImage; e += kThreads) {
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) sum += tbuf[w * kImage + e];
+            dst[arr * kImage + e] = sum;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+}  // namespace pde

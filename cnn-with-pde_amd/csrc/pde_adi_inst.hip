@@ -1,0 +1,69 @@
+// One translation unit per line length: compile with -DPDE_INST_N=<N>.
+#include "pde_adi_dev.h"
+#include "pde_adi_launch.h"
+
+#include <mutex>
+
+#ifndef PDE_INST_N
+#error "compile with -DPDE_INST_N=<line length>"
+#endif
+
+#define PDE_CAT2(a, b) a##b
+#define PDE_CAT(a, b) PDE_CAT2(a, b)
+
+namespace pde {
+namespace {
+
+template <typename K>
+int launch(K kernel, const SweepArgs& sa, int grid, size_t lds, hipStream_t st) {
+    static std::mutex mu;
+    static bool configured = false;                 // one static per kernel instantiation
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!configured) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds) != hipSuccess)
+                return PDE_E_LAUNCH;
+            configured = true;
+        }
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), lds, st, sa);
+    return check_launch();
+}
+
+template <typename IO>
+int fwd_io(int split, const SweepArgs& sa, int grid, size_t lds, hipStream_t st) {
+    constexpr int N = PDE_INST_N;
+    switch (split) {
+        case kSplitStrang: return launch(adi_fwd_kernel<N, kJFwd, IO, kSplitStrang>, sa, grid, lds, st);
+        case kSplitLie: return launch(adi_fwd_kernel<N, kJFwd, IO, kSplitLie>, sa, grid, lds, st);
+        default: return launch(adi_fwd_kernel<N, kJFwd, IO, kSplitAny>, sa, grid, lds, st);
+    }
+}
+
+template <typename IO>
+int bwd_io(int split, int masked, const SweepArgs& sa, int grid, size_t lds, hipStream_t st) {
+    constexpr int N = PDE_INST_N;
+    if (masked) return launch(adi_bwd_kernel<N, 1, IO, true, kSplitAny>, sa, grid, lds, st);   // rare path
+    switch (split) {
+        case kSplitStrang: return launch(adi_bwd_kernel<N, kJBwd, IO, false, kSplitStrang>, sa, grid, lds, st);
+        case kSplitLie: return launch(adi_bwd_kernel<N, kJBwd, IO, false, kSplitLie>, sa, grid, lds, st);
+        default: return launch(adi_bwd_kernel<N, 1, IO, false, kSplitAny>, sa, grid, lds, st);
+    }
+}
+
+}  // namespace
+
+int PDE_CAT(adi_launch_fwd_, PDE_INST_N)(int io, int split, const void* args, int grid, size_t lds, hipStream_t st) {
+    const SweepArgs& sa = *static_cast<const SweepArgs*>(args);
+    return io == PDE_IO_F32 ? fwd_io<float>(split, sa, grid, lds, st) : fwd_io<bf16_t>(split, sa, grid, lds, st);
+}
+
+int PDE_CAT(adi_launch_bwd_, PDE_INST_N)(int io, int split, int masked, const void* args, int grid, size_t lds,
+                                         hipStream_t st) {
+    const SweepArgs& sa = *static_cast<const SweepArgs*>(args);
+    return io == PDE_IO_F32 ? bwd_io<float>(split, masked, sa, grid, lds, st)
+                            : bwd_io<bf16_t>(split, masked, sa, grid, lds, st);
+}
+
+}  // namespace pde
