@@ -44,9 +44,9 @@ _D = C.POINTER(PdeAdiDesc)
 SIGNATURES = {
     "pde_adi_forward_workspace_bytes": (_sz, [_D]),
     "pde_adi_backward_workspace_bytes": (_sz, [_D, _i32]),
-    "pde_adi_forward": (C.c_int, [_D, _vp, _vp, _fp, _fp, _fp, _fp, _vp, _sz, _vp]),
+    "pde_adi_forward": (C.c_int, [_D, _vp, _vp, _fp, _fp, _fp, _fp, _fp, _vp, _sz, _vp]),
     "pde_adi_backward": (C.c_int, [_D, _vp, _vp, _vp, C.POINTER(C.c_uint64), _vp, _fp, _fp, _fp, _fp,
-                                   _fp, _fp, _fp, _fp, _vp, _sz, _vp]),
+                                   _fp, _fp, _fp, _fp, _vp, _vp, _sz, _vp]),
     "pde_adi_kappa_max": (C.c_int, [_D, _fp, _fp, _fp, _fp, _fp, _vp]),
     "pde_channel_mix_forward": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _fp, _vp, _vp]),
     "pde_channel_mix_backward_workspace_bytes": (_sz, [_i32, _i32, _i32]),

@@ -62,12 +62,13 @@ struct FactorArgs {
     PdeSweep sweep[PDE_MAX_SWEEPS];
 };
 
+template <int N>
 __global__ __launch_bounds__(64) void adi_factor_kernel(FactorArgs a) {
     // one wave = two records (sweep s, channels 2p and 2p+1); lane = (record, line).  Records are
     // built in LDS and written out as whole 16-byte rows: a line-per-thread store straight to
     // global memory is a 4-byte scatter and ran 10x slower.
     __shared__ __attribute__((aligned(16))) float rec_s[2][kRecStride];
-    const int N = a.N, m = N / 2;
+    constexpr int m = N / 2;
     const int pairs = (a.C + 1) / 2;
     const int s = blockIdx.x / pairs;
     const int which = threadIdx.x >> 5;
@@ -90,6 +91,7 @@ __global__ __launch_bounds__(64) void adi_factor_kernel(FactorArgs a) {
         a.tab->t_last[ax] = tlast;
     }
     float* rec = rec_s[which];
+    float kmax_lane = 0.f;
     const PdeSweep sw = a.sweep[s];
     const bool xax = sw.axis == PDE_AXIS_X;
     const bool live = (c < a.C) && (line < N);
@@ -109,10 +111,11 @@ __global__ __launch_bounds__(64) void adi_factor_kernel(FactorArgs a) {
         const size_t cbase = (size_t)c * N * N;
         const int st = xax ? 1 : N;                 // stride between consecutive unknowns of my line
         const int o0 = xax ? line * N : line;
-        float kap[PDE_MAX_N];
-        float pass[PDE_MAX_N];
+        float kap[N];
+        float pass[N];
         bool differs = false;
         // theta = clamp(base + slope*t, eps[, max])          mnist_test.py:33-42
+#pragma unroll
         for (int i = 0; i < N; ++i) {
             const float bs = base[cbase + o0 + i * st], sl = slope[cbase + o0 + i * st];
             float th = bs + sl * sw.t;
@@ -129,6 +132,7 @@ __global__ __launch_bounds__(64) void adi_factor_kernel(FactorArgs a) {
         if (a.smooth3) {                             // mnist_test.py:135-149 (replicate ends)
             const float third = 1.0f / 3.0f;
             float prev = kap[0];
+#pragma unroll
             for (int i = 0; i < N; ++i) {
                 const float cur = kap[i];
                 const float nxt = kap[i + 1 < N ? i + 1 : N - 1];
@@ -136,14 +140,22 @@ __global__ __launch_bounds__(64) void adi_factor_kernel(FactorArgs a) {
                 prev = cur;
             }
         }
-        for (int i = 0; i < N; ++i) kap[i] = (kap[i] * sw.delta) / sw.h2;     // coeff = theta*dt/dx**2  mnist_test.py:83
+        float km = 0.f;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            kap[i] = (kap[i] * sw.delta) / sw.h2;     // coeff = theta*dt/dx**2  mnist_test.py:83
+            km = fmaxf(km, kap[i]);
+        }
+        kmax_lane = km;
         float* inv_row = rec + kRecInv + line * kLineStride;
         float* e_row = rec + kRecE + line * kLineStride;
         float e_in[2];
         // two-sided elimination of (A + eps I): rows i = k (hf 0) and i = N-1-k (hf 1),
         // den_k = b_k - kap_k * (kap_{k-1}/den_{k-1}) + eps       mnist_test.py:169,177
+#pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
             float e = 0.f;                           // kap_{k-1}/den_{k-1} of the outer neighbour
+#pragma unroll
             for (int k = 0; k < m; ++k) {
                 const int i = hf ? N - 1 - k : k;
                 const float kp = kap[i];
@@ -161,17 +173,23 @@ __global__ __launch_bounds__(64) void adi_factor_kernel(FactorArgs a) {
         float* kx = rec + kRecKapX;
         float* mx = rec + kRecMaskX;
         if (xax) {
+#pragma unroll
             for (int i = 0; i < N; ++i) {
                 kx[line * kLineStride + half_pos(i, N)] = kap[i];
                 mx[line * kLineStride + half_pos(i, N)] = pass[i];
             }
         } else {
             const int p = half_pos(line, N);
+#pragma unroll
             for (int i = 0; i < N; ++i) {
                 kx[i * kLineStride + p] = kap[i];
                 mx[i * kLineStride + p] = pass[i];
             }
         }
+    }
+    if (a.kmax) {                                    // per-sweep maximum coefficient: one atomic per wave
+        for (int o = 32; o > 0; o >>= 1) kmax_lane = fmaxf(kmax_lane, __shfl_xor(kmax_lane, o, 64));
+        if (threadIdx.x == 0) atomicMax((unsigned int*)&a.kmax[s], __float_as_uint(kmax_lane));   // values are > 0
     }
     __syncthreads();
     for (int w = 0; w < 2; ++w) {
@@ -344,11 +362,17 @@ void fill_factor_args(FactorArgs& fa, const PdeAdiDesc* d, const float* ab, cons
 }
 
 int launch_factor(const PdeAdiDesc* d, const float* ab, const float* bb, const float* as, const float* bs,
-                  float* coef, SweepTab* tab, int* varying, hipStream_t st) {
+                  float* coef, SweepTab* tab, int* varying, float* kmax, hipStream_t st) {
     FactorArgs fa;
     fill_factor_args(fa, d, ab, bb, as, bs);
-    fa.coef = coef; fa.tab = tab; fa.varying = varying;
-    hipLaunchKernelGGL(adi_factor_kernel, dim3(d->num_sweeps * ((d->C + 1) / 2)), dim3(64), 0, st, fa);
+    fa.coef = coef; fa.tab = tab; fa.varying = varying; fa.kmax = kmax;
+    const dim3 grid(d->num_sweeps * ((d->C + 1) / 2));
+    switch (d->N) {
+#define PDE_CASE(NN) case NN: hipLaunchKernelGGL(adi_factor_kernel<NN>, grid, dim3(64), 0, st, fa); break;
+        PDE_CASE(8) PDE_CASE(12) PDE_CASE(16) PDE_CASE(20) PDE_CASE(24) PDE_CASE(28) PDE_CASE(32)
+#undef PDE_CASE
+        default: return PDE_E_UNSUPPORTED_N;
+    }
     return check_launch();
 }
 
@@ -429,7 +453,7 @@ extern "C" {
 
 size_t pde_adi_forward_workspace_bytes(const PdeAdiDesc* d) {
     if (check_desc(d) != PDE_OK) return 0;
-    return coef_bytes(d) + tab_bytes();
+    return coef_bytes(d) + tab_bytes() + flag_bytes(d);
 }
 
 size_t pde_adi_backward_workspace_bytes(const PdeAdiDesc* d, int32_t num_checkpoints) {
@@ -442,8 +466,8 @@ size_t pde_adi_backward_workspace_bytes(const PdeAdiDesc* d, int32_t num_checkpo
 }
 
 int pde_adi_forward(const PdeAdiDesc* d, const void* u, void* y, const float* alpha_base, const float* beta_base,
-                    const float* alpha_slope, const float* beta_slope, void* workspace, size_t workspace_bytes,
-                    void* stream) {
+                    const float* alpha_slope, const float* beta_slope, float* kappa_max, void* workspace,
+                    size_t workspace_bytes, void* stream) {
     int rc = check_desc(d);
     if (rc != PDE_OK) return rc;
     if (!u || !y || !alpha_base || !beta_base || !alpha_slope || !beta_slope || !workspace) return PDE_E_BADARG;
@@ -451,7 +475,11 @@ int pde_adi_forward(const PdeAdiDesc* d, const void* u, void* y, const float* al
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* coef = static_cast<float*>(workspace);
     SweepTab* tab = reinterpret_cast<SweepTab*>(static_cast<char*>(workspace) + coef_bytes(d));
-    rc = launch_factor(d, alpha_base, beta_base, alpha_slope, beta_slope, coef, tab, nullptr, st);
+    int* varying = reinterpret_cast<int*>(static_cast<char*>(workspace) + coef_bytes(d) + tab_bytes());
+    if (hipMemsetAsync(varying, 0, flag_bytes(d), st) != hipSuccess) return PDE_E_LAUNCH;
+    if (kappa_max && hipMemsetAsync(kappa_max, 0, (size_t)d->num_sweeps * sizeof(float), st) != hipSuccess)
+        return PDE_E_LAUNCH;
+    rc = launch_factor(d, alpha_base, beta_base, alpha_slope, beta_slope, coef, tab, varying, kappa_max, st);
     if (rc != PDE_OK) return rc;
     SweepArgs sa{};
     sa.in0 = u; sa.out = y; sa.coef = coef; sa.tab = tab;
@@ -465,7 +493,8 @@ int pde_adi_forward(const PdeAdiDesc* d, const void* u, void* y, const float* al
 int pde_adi_backward(const PdeAdiDesc* d, const void* gy, const void* y, const void* u, const uint64_t ckpt_mask[2],
                      void* gu, const float* alpha_base, const float* beta_base, const float* alpha_slope,
                      const float* beta_slope, float* g_alpha_base, float* g_beta_base, float* g_alpha_slope,
-                     float* g_beta_slope, void* workspace, size_t workspace_bytes, void* stream) {
+                     float* g_beta_slope, const void* fwd_workspace, void* workspace, size_t workspace_bytes,
+                     void* stream) {
     int rc = check_desc(d);
     if (rc != PDE_OK) return rc;
     if (!gy || !y || !gu || !alpha_base || !beta_base || !alpha_slope || !beta_slope || !g_alpha_base ||
@@ -490,9 +519,18 @@ int pde_adi_backward(const PdeAdiDesc* d, const void* gy, const void* y, const v
     int* varying = reinterpret_cast<int*>(ws);            ws += flag_bytes(d);
     float* part = reinterpret_cast<float*>(ws);           ws += align_up((size_t)G * d->C * 4 * kImage * sizeof(float), 256);
     float* ckpt = reinterpret_cast<float*>(ws);
-    if (hipMemsetAsync(varying, 0, flag_bytes(d), st) != hipSuccess) return PDE_E_LAUNCH;
-    rc = launch_factor(d, alpha_base, beta_base, alpha_slope, beta_slope, coef, tab, varying, st);
-    if (rc != PDE_OK) return rc;
+    if (fwd_workspace) {
+        // the forward call of the same step left the factorisation, the sweep table and the
+        // channel flags in its workspace: read them from there instead of recomputing
+        const char* fw = static_cast<const char*>(fwd_workspace);
+        coef = reinterpret_cast<float*>(const_cast<char*>(fw));
+        tab = reinterpret_cast<SweepTab*>(const_cast<char*>(fw + coef_bytes(d)));
+        varying = reinterpret_cast<int*>(const_cast<char*>(fw + coef_bytes(d) + tab_bytes()));
+    } else {
+        if (hipMemsetAsync(varying, 0, flag_bytes(d), st) != hipSuccess) return PDE_E_LAUNCH;
+        rc = launch_factor(d, alpha_base, beta_base, alpha_slope, beta_slope, coef, tab, varying, nullptr, st);
+        if (rc != PDE_OK) return rc;
+    }
 
     SweepArgs sa{};
     sa.in0 = gy; sa.in1 = y; sa.in2 = u; sa.out = gu; sa.coef = coef; sa.part = part; sa.tab = tab;

@@ -43,6 +43,15 @@ struct SweepArgs {
     float one_eps;          // 1 + eps
 };
 
+// The sweep table and the channel flags are written by an earlier kernel and only read here.
+// Reading them through the constant address space makes hipcc use scalar loads; through a plain
+// global pointer it issues VECTOR loads followed by s_waitcnt vmcnt(0), which also drains the
+// coefficient prefetch that was just issued (measured: a full memory round trip per sweep).
+typedef const __attribute__((address_space(4))) SweepTab* ConstTab;
+typedef const __attribute__((address_space(4))) int* ConstInt;
+__device__ __forceinline__ ConstTab as_const(const SweepTab* p) { return (ConstTab)(unsigned long long)p; }
+__device__ __forceinline__ ConstInt as_const(const int* p) { return (ConstInt)(unsigned long long)p; }
+
 __device__ __forceinline__ float xchg_half(float v) {     // value held by lane ^ 32
     return __shfl_xor(v, 32, 64);
 }
@@ -330,6 +339,7 @@ __global__ __launch_bounds__(kThreads) void adi_fwd_kernel(SweepArgs a) {
     float* T = tbuf + wave * kImage;
     const IO* u = static_cast<const IO*>(a.in0);
     IO* y = static_cast<IO*>(a.out);
+    const ConstTab tab = as_const(a.tab);
     constexpr int PPI = kWaves * J;                       // planes per workgroup iteration
     const int nchunk = (a.B + PPI - 1) / PPI;
     const size_t plane = (size_t)N * N;
@@ -352,7 +362,7 @@ __global__ __launch_bounds__(kThreads) void adi_fwd_kernel(SweepArgs a) {
             const bool pre = (s + 1 < a.S) || more;
             if (pre) stage_load<kRecFwd>(a.coef + ((size_t)snext * a.C + c) * kRecStride, tid, st0, st1, st2);
             const float* rec = cbuf + (n & 1) * kRecFwd;
-            const int axs = (AX >= 0) ? AX : a.tab->axis[s];
+            const int axs = (AX >= 0) ? AX : tab->axis[s];
             if (axs == PDE_AXIS_Y) {
 #pragma unroll
                 for (int j = 0; j < J; ++j) relayout<N>(v[j], T, l, hf);
@@ -517,7 +527,8 @@ __global__ __launch_bounds__(kThreads) void adi_bwd_kernel(SweepArgs a) {
     constexpr int M = Geo<N>::M;
     constexpr int REC = MASKED ? kRecStride : kRecBwd;
     const int c = blockIdx.x % a.C, g = blockIdx.x / a.C;
-    if ((a.varying[c] != 0) != MASKED) return;            // the other instantiation owns this channel
+    if ((as_const(a.varying)[c] != 0) != MASKED) return;  // the other instantiation owns this channel
+    const ConstTab tab = as_const(a.tab);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* cbuf = smem;                                   // [2][REC]
     float* tbuf = smem + 2 * REC;                         // [kWaves][kImage]
@@ -557,9 +568,9 @@ __global__ __launch_bounds__(kThreads) void adi_bwd_kernel(SweepArgs a) {
             const bool pre = (s > 0) || more;
             if (pre) stage_load<REC>(a.coef + ((size_t)snext * a.C + c) * kRecStride, tid, st0, st1, st2);
             const float* rec = cbuf + (n & 1) * REC;
-            const int axs = (AX >= 0) ? AX : a.tab->axis[s];
-            float dts = a.tab->dts[s];
-            if (more && s == a.tab->first_s[axs]) dts -= a.tab->t_last[axs];
+            const int axs = (AX >= 0) ? AX : tab->axis[s];
+            float dts = tab->dts[s];
+            if (more && s == tab->first_s[axs]) dts -= tab->t_last[axs];
             if (axs == PDE_AXIS_Y) {
 #pragma unroll
                 for (int j = 0; j < J; ++j) relayout<N>(r[j], T, l, hf);

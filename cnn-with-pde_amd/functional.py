@@ -137,7 +137,7 @@ def kappa_max_async(u_like, alpha_base, beta_base, alpha_time_coeff, beta_time_c
 
 class _AdiFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, u, ab, bb, asl, bsl, sweeps, smooth3, clamp_max, eps, ckpt):
+    def forward(ctx, u, ab, bb, asl, bsl, sweeps, smooth3, clamp_max, eps, ckpt, kmax_sink):
         lib = L.load()
         _require_cuda(u, ab, bb, asl, bsl)
         if u.dim() != 4 or u.shape[2] != u.shape[3]:
@@ -151,22 +151,24 @@ class _AdiFn(torch.autograd.Function):
         y = torch.empty_like(u)
         nbytes = lib.pde_adi_forward_workspace_bytes(C.byref(d))
         ws = _workspace(nbytes, u.device)
-        with torch.cuda.device(u.device):
-            L.check(lib.pde_adi_forward(C.byref(d), _ptr(u), _ptr(y), *[_ptr(t) for t in p],
-                                        _ptr(ws), ws.numel(), _stream()), "pde_adi_forward")
-        ctx.kmax_host = ctx.kmax_event = None
         need_grad = any(ctx.needs_input_grad[:5])
-        if need_grad and ckpt == "auto":
-            # per-sweep maximum coefficient, copied to the host asynchronously: the backward (which
-            # runs after the rest of the model) picks its checkpoints from it without a stall
-            kdev = torch.empty(len(sweeps), dtype=torch.float32, device=u.device)
-            with torch.cuda.device(u.device):
-                L.check(lib.pde_adi_kappa_max(C.byref(d), *[_ptr(t) for t in p], _ptr(kdev), _stream()),
-                        "pde_adi_kappa_max")
-                ctx.kmax_host = torch.empty(len(sweeps), dtype=torch.float32, pin_memory=True)
-                ctx.kmax_host.copy_(kdev, non_blocking=True)
-                ctx.kmax_event = torch.cuda.Event()
-                ctx.kmax_event.record()
+        want_kmax = need_grad and (ckpt == "auto" or kmax_sink is not None)
+        kdev = torch.empty(len(sweeps), dtype=torch.float32, device=u.device) if want_kmax else None
+        with torch.cuda.device(u.device):
+            L.check(lib.pde_adi_forward(C.byref(d), _ptr(u), _ptr(y), *[_ptr(t) for t in p], _ptr(kdev),
+                                        _ptr(ws), ws.numel(), _stream()), "pde_adi_forward")
+            ctx.kmax_host = ctx.kmax_event = None
+            if want_kmax:
+                # per-sweep maximum coefficient (a by-product of the factorisation kernel), copied to
+                # the host asynchronously: whoever plans checkpoints reads it later without a stall
+                host = torch.empty(len(sweeps), dtype=torch.float32, pin_memory=True)
+                host.copy_(kdev, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                ctx.kmax_host, ctx.kmax_event = host, ev
+                if kmax_sink is not None:
+                    kmax_sink.append((host, ev))
+        ctx.fwd_ws = ws if need_grad else None       # factorisation reused by the backward
         ctx.save_for_backward(y, u if (need_grad and ckpt != 0) else None, *p)
         ctx.cfg = (sweeps, smooth3, clamp_max, eps, ckpt)
         ctx.param_shapes = [t.shape for t in (ab, bb, asl, bsl)]
@@ -192,14 +194,16 @@ class _AdiFn(torch.autograd.Function):
         ws = _workspace(nbytes, y.device)
         with torch.cuda.device(y.device):          # autograd thread: set device, fetch the stream here
             L.check(lib.pde_adi_backward(C.byref(d), _ptr(gy), _ptr(y), _ptr(u if bits else None), mask, _ptr(gu),
-                                         *[_ptr(t) for t in p], *[_ptr(t) for t in gp],
+                                         *[_ptr(t) for t in p], *[_ptr(t) for t in gp], _ptr(ctx.fwd_ws),
                                          _ptr(ws), ws.numel(), _stream()), "pde_adi_backward")
+        ctx.fwd_ws = None
         gp = [g.reshape(s) for g, s in zip(gp, ctx.param_shapes)]
-        return (gu, *gp, None, None, None, None, None)
+        return (gu, *gp, None, None, None, None, None, None)
 
 
 def adi_diffuse(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff, sweeps: Sequence[Sweep],
-                smooth3: bool = False, clamp_max: Optional[float] = None, eps: float = 1e-6, checkpoints="auto"):
+                smooth3: bool = False, clamp_max: Optional[float] = None, eps: float = 1e-6, checkpoints="auto",
+                kmax_sink: Optional[list] = None):
     """Run ``sweeps`` (a flat list) of implicit diffusion on ``u`` (B,C,N,N) in one fused launch.
 
     Replaces the reference's time loop over diffuse_x/diffuse_y/thomas_solver_batch
@@ -207,9 +211,11 @@ def adi_diffuse(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff, swe
 
     ``checkpoints``: "auto" (default) chooses the backward's checkpoints from the coefficients
     (``plan_checkpoints``); an int is an explicit bit mask (0: rebuild every state from the output).
+    ``kmax_sink``: a list that receives ``(pinned_host_tensor, event)`` with the per-sweep maximum
+    coefficient of this call (valid once the event has completed).
     """
     return _AdiFn.apply(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff, tuple(sweeps),
-                        bool(smooth3), clamp_max, float(eps), checkpoints)
+                        bool(smooth3), clamp_max, float(eps), checkpoints, kmax_sink)
 
 
 # --------------------------------------------------------------------------- channel mixing

@@ -57,24 +57,24 @@ class _AdiBase(nn.Module):
     def _diffuse(self, u, sweeps):
         args = (self.alpha_base, self.beta_base, self.alpha_time_coeff, self.beta_time_coeff)
         kw = dict(smooth3=self._smooth3, clamp_max=self._clamp_max, eps=self.stability_eps)
-        ck = self.checkpoint_policy
+        ck, sink = self.checkpoint_policy, None
         if ck == "lagged":
             if not (torch.is_grad_enabled() and (u.requires_grad or any(p.requires_grad for p in args))):
                 ck = 0
             else:
                 cache = self.__dict__.setdefault("_kmax_cache", {})
                 key = (len(sweeps), sweeps[0].t, u.device)
-                fresh = F_.kappa_max_async(u, *args, sweeps, **kw)
                 old = cache.get(key)
-                if old is None:
-                    fresh[1].synchronize()                 # first call only
-                    bits = F_.plan_checkpoints(fresh[0].tolist(), F_.CKPT_AMAX / 2)
+                if old is None:                            # first call only: wait for the coefficients
+                    host, ev = F_.kappa_max_async(u, *args, sweeps, **kw)
+                    ev.synchronize()
+                    old = (host, ev, F_.plan_checkpoints(host.tolist(), F_.CKPT_AMAX / 2))
                 elif old[1].query():
-                    bits = F_.plan_checkpoints(old[0].tolist(), F_.CKPT_AMAX / 2)
-                else:
-                    bits = old[2]
-                cache[key] = (fresh[0], fresh[1], bits)
-                ck = bits
+                    old = (old[0], old[1], F_.plan_checkpoints(old[0].tolist(), F_.CKPT_AMAX / 2))
+                ck, sink = old[2], []
+                y = F_.adi_diffuse(u, *args, sweeps, checkpoints=ck, kmax_sink=sink, **kw)
+                cache[key] = (sink[0][0], sink[0][1], ck) if sink else old
+                return y
         return F_.adi_diffuse(u, *args, sweeps, checkpoints=ck, **kw)
 
 

@@ -70,11 +70,15 @@ size_t pde_adi_backward_workspace_bytes(const PdeAdiDesc* d, int32_t num_checkpo
 /* y = (prod_s (A_s + eps I)^-1) u.  Replaces DiffusionLayer.forward's time loop with its
  * diffuse_x/diffuse_y/thomas_solver_batch calls (mnist_test.py:44-198; cifar10.py:74-211
  * without apply_channel_mixing, which is pde_channel_mix_*).
- * alpha_xxx / beta_xxx: (C,N,N) fp32.  u, y: (B,C,N,N) of io_dtype; y must not alias u. */
+ * alpha_xxx / beta_xxx: (C,N,N) fp32.  u, y: (B,C,N,N) of io_dtype; y must not alias u.
+ * kappa_max: NULL, or a device buffer of num_sweeps floats that receives the maximum
+ * coefficient of every sweep (same values as pde_adi_kappa_max, at no extra launch).
+ * After the call the workspace holds the factorisation of every sweep; while it stays intact it
+ * may be handed to pde_adi_backward as fwd_workspace to skip refactorising. */
 int pde_adi_forward(const PdeAdiDesc* d, const void* u, void* y,
                     const float* alpha_base, const float* beta_base,
                     const float* alpha_slope, const float* beta_slope,
-                    void* workspace, size_t workspace_bytes, void* stream);
+                    float* kappa_max, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Exact reverse-mode derivative of pde_adi_forward (the reference gets it from autograd,
  * SURVEY.md §3d).  Inputs: gy = dL/dy, y = forward output.  Outputs: gu = dL/du and the
@@ -91,6 +95,8 @@ int pde_adi_backward(const PdeAdiDesc* d, const void* gy, const void* y, const v
                      const float* alpha_slope, const float* beta_slope,
                      float* g_alpha_base, float* g_beta_base,
                      float* g_alpha_slope, float* g_beta_slope,
+                     const void* fwd_workspace /* NULL, or the intact workspace of the matching
+                                                  pde_adi_forward call (same desc, same parameters) */,
                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* max over the tensor of coeff_s = theta_s*delta_s/h2_s for every sweep, written to
