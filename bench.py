@@ -54,11 +54,7 @@ def run_steps(layer, u, gy, n, dist_on, flat):
         y = layer(u)
         y.backward(gy)
         if dist_on:
-            import torch.distributed as dist
-            grads = [p.grad for p in layer.parameters() if p.grad is not None]
-            torch._foreach_copy_(list(flat.split([g.numel() for g in grads])), [g.reshape(-1) for g in grads])
-            dist.all_reduce(flat)               # one flat bucket (1.06 MB): latency-bound over xGMI
-            flat.div_(dist.get_world_size())
+            flat.allreduce(average=True)        # one flat bucket (1.06 MB): latency-bound over xGMI
 
 
 def timed(layer, u, gy, steps, warmup, dist_on, flat):
@@ -151,8 +147,8 @@ def main():
     u = torch.randn(B, C, N, N, generator=g).to(dev).requires_grad_(True)
     gy = torch.randn(B, C, N, N, generator=g).to(dev)
     layer = build_layer(C, N, steps, dev, rank, mixing=False)
-    nparam = sum(p.numel() for p in layer.parameters())
-    flat = torch.empty(nparam - layer.channel_mixing.numel(), device=dev) if dist_on else None
+    layer.channel_mixing.requires_grad_(False)          # unused when mixing is disabled
+    flat = P.GradBucket(layer.parameters()) if dist_on else None
 
     dt = timed(layer, u, gy, a.steps, a.warmup, dist_on, flat)
     ms_step = dt / a.steps * 1e3
@@ -182,7 +178,7 @@ def main():
                                    f"fwd+bwd, {3 * steps} implicit sweeps, batch {B}/GPU, channel mixing disabled "
                                    "(BASELINE configs[1], SURVEY §8d cfg2 primary)",
                        "global_batch": B * world, "parallelism": f"dp{world}",
-                       "grad_allreduce_bytes": (flat.numel() * 4 if flat is not None else 0)},
+                       "grad_allreduce_bytes": (flat.nbytes() if flat is not None else 0)},
             "roofline": {"bound": "hbm", "kernel": "adi_bwd_kernel", "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc,
                          "algorithmic_bytes_per_launch": elems * BYTES_PER_ELEM["bwd"], "avg_launch_ms": bwd_ms},
@@ -196,7 +192,7 @@ def main():
 
     if not a.no_secondary:
         layer2 = build_layer(C, N, steps, dev, rank, mixing=True)
-        flat2 = torch.empty(nparam, device=dev) if dist_on else None
+        flat2 = P.GradBucket(layer2.parameters()) if dist_on else None
         k2 = max(3, a.steps // 5)
         dt2 = timed(layer2, u, gy, k2, 2, dist_on, flat2)
         if rank == 0:

@@ -3,6 +3,7 @@ from . import _lib
 from ._lib import PdeError, LIB_PATH
 from .functional import (Sweep, adi_schedule, adi_diffuse, plan_checkpoints, channel_mix, explicit5_step, jacobi_diffuse,
                          timing_enable, timing_read)
+from .dist import shard_range, shard_batch, GradBucket
 from .layers import (MnistDiffusionLayer, FashionDiffusionLayer, SvhnDiffusionLayer, EnhancedDiffusionLayer,
                      LearnableDiffusionLayer, ImprovedDiffusionLayer, PDELayer)
 
@@ -25,4 +26,4 @@ def library_version() -> str:
 __all__ = ["PdeError", "LIB_PATH", "Sweep", "adi_schedule", "adi_diffuse", "plan_checkpoints", "channel_mix", "explicit5_step",
            "jacobi_diffuse", "timing_enable", "timing_read", "MnistDiffusionLayer", "FashionDiffusionLayer",
            "SvhnDiffusionLayer", "EnhancedDiffusionLayer", "LearnableDiffusionLayer", "ImprovedDiffusionLayer",
-           "PDELayer", "REFERENCE_CLASSES", "library_version"]
+           "PDELayer", "REFERENCE_CLASSES", "library_version", "shard_range", "shard_batch", "GradBucket"]

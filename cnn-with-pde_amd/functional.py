@@ -122,6 +122,7 @@ def kappa_max_async(u_like, alpha_base, beta_base, alpha_time_coeff, beta_time_c
     """Launch the per-sweep max-coefficient kernel and an asynchronous copy to pinned host memory.
     Returns (host_tensor, event); the values are valid once ``event.query()`` is True."""
     lib = L.load()
+    _require_cuda(u_like, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff)
     B, Cc, N, _ = u_like.shape
     p = [_as_chw(t, Cc, N) for t in (alpha_base, beta_base, alpha_time_coeff, beta_time_coeff)]
     d = _make_desc(B, Cc, N, L.PDE_IO_F32, sweeps, smooth3, clamp_max, eps)

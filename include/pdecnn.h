@@ -88,7 +88,9 @@ int pde_adi_forward(const PdeAdiDesc* d, const void* u, void* y,
  * after sweep s, read it from a checkpoint instead; the kernel then first recomputes the
  * forward from `u` to write those checkpoints into the workspace.  ckpt_mask == 0 needs
  * neither u nor checkpoint space (u may be NULL).  Bits are given low word first:
- * sweep s is bit (s%64) of ckpt_mask[s/64]. */
+ * sweep s is bit (s%64) of ckpt_mask[s/64].
+ * Restriction: all sweeps of one axis must share delta/h2 (true for every reference variant:
+ * Strang x(dt/2) y(dt) x(dt/2), Lie x(dt/2) y(dt/2)); otherwise PDE_E_BADARG. */
 int pde_adi_backward(const PdeAdiDesc* d, const void* gy, const void* y, const void* u,
                      const uint64_t ckpt_mask[2], void* gu,
                      const float* alpha_base, const float* beta_base,

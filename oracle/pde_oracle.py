@@ -287,22 +287,27 @@ def emotion_coefficients(params: Dict[str, torch.Tensor], Nx=48, Ny=48, Lx=1.0, 
     return A, Bc
 
 
-def emotion_forward(u0: torch.Tensor, params: Dict[str, torch.Tensor], Nx=48, Ny=48, Lx=1.0, Ly=1.0,
-                    T=0.01, dt=0.001) -> torch.Tensor:
-    """emotion_recognition.py:82-97: reflect-pad once, Nt Jacobi updates of the
-    interior, the padded ring keeps its initial values."""
-    Nt = int(T / dt)
-    A, Bc = emotion_coefficients(params, Nx, Ny, Lx, Ly, dt, u0.dtype)
-    P = F.pad(u0.squeeze(1), (1, 1, 1, 1), mode="reflect")
-    A = A.view(1, -1, 1)           # varies along dim 1 (rows)
-    Bc = Bc.view(1, 1, -1)         # varies along dim 2 (columns)
-    for _ in range(Nt):
+def jacobi_forward(u: torch.Tensor, A: torch.Tensor, Bc: torch.Tensor, nt: int) -> torch.Tensor:
+    """The time loop of emotion_recognition.py:85-97 for given coefficient vectors: u (B,H,W),
+    A (H,) multiplies the second difference along dim 1, Bc (W,) the one along dim 2."""
+    P = F.pad(u, (1, 1, 1, 1), mode="reflect")
+    A = A.view(1, -1, 1)
+    Bc = Bc.view(1, 1, -1)
+    for _ in range(nt):
         inner = P[:, 1:-1, 1:-1]
         d1 = P[:, 2:, 1:-1] - 2 * inner + P[:, :-2, 1:-1]
         d2 = P[:, 1:-1, 2:] - 2 * inner + P[:, 1:-1, :-2]
         new = inner + A * d1 + Bc * d2
         P = torch.cat([P[:, :1], torch.cat([P[:, 1:-1, :1], new, P[:, 1:-1, -1:]], dim=2), P[:, -1:]], dim=1)
-    return P[:, 1:-1, 1:-1].unsqueeze(1)
+    return P[:, 1:-1, 1:-1]
+
+
+def emotion_forward(u0: torch.Tensor, params: Dict[str, torch.Tensor], Nx=48, Ny=48, Lx=1.0, Ly=1.0,
+                    T=0.01, dt=0.001) -> torch.Tensor:
+    """emotion_recognition.py:82-97: reflect-pad once, Nt Jacobi updates of the
+    interior, the padded ring keeps its initial values."""
+    A, Bc = emotion_coefficients(params, Nx, Ny, Lx, Ly, dt, u0.dtype)
+    return jacobi_forward(u0.squeeze(1), A, Bc, int(T / dt)).unsqueeze(1)
 
 
 def emotion_init_params(dtype=torch.float32) -> Dict[str, torch.Tensor]:
