@@ -104,9 +104,24 @@ def cpu_baseline(C, N, steps, sample_B):
     nb = int(max(2, min(sample_B, 2 * 20.0 / max(probe, 1e-3))))
     print(f"[bench] cpu_baseline probe {probe:.1f} s for 2 samples; timing {nb} samples", file=sys.stderr, flush=True)
     dt = once(nb)
-    return {"value": nb / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": f"B={nb} of the same (C={C},{N}x{N},{steps} steps) workload, one fwd+bwd, "
-                      f"oracle/pde_oracle.py in reference-faithful mode ({dt:.1f} s on {cores} threads)"}
+    out = {"value": nb / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+           "sample": f"B={nb} of the same (C={C},{N}x{N},{steps} steps) workload, one fwd+bwd, "
+                     f"oracle/pde_oracle.py in reference-faithful mode ({dt:.1f} s on {cores} threads)"}
+    try:                                        # also: the C restatement with closed-form gradients (OpenMP)
+        from oracle import c_oracle as CO
+        if CO.available():
+            os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+            nb2 = 64
+            u = torch.randn(nb2, C, N, N, generator=g)
+            gy = torch.randn(nb2, C, N, N, generator=g)
+            t0 = time.perf_counter()
+            CO.adi_value_and_grads(u, params, gy, spec)
+            dt2 = time.perf_counter() - t0
+            out["c_restatement"] = {"value": nb2 / dt2 / 1e6, "unit": "Msamples/s",
+                                    "sample": f"B={nb2}, oracle/pde_oracle_c.c fp32, OpenMP {cores} threads, {dt2:.2f} s"}
+    except Exception as e:                      # the checker's availability must not break the bench
+        out["c_restatement"] = {"error": repr(e)}
+    return out
 
 
 def main():

@@ -277,3 +277,30 @@ def test_full_size_adjoint_identity_and_additivity(big):
                 acc[n] += p.grad
     for n in full:
         assert G.rel_err(acc[n].cpu(), full[n].cpu()) <= TOL, n
+
+
+def test_mid_size_against_c_oracle():
+    """BASELINE configs[1] semantics at a size the C restatement (closed-form gradients, OpenMP)
+    finishes in seconds: 48 x 16 x 32 x 32, 10 Strang steps, trained-like coefficients."""
+    from oracle import c_oracle as CO
+    if not CO.available():
+        pytest.skip("oracle/libpde_oracle_c.so not built")
+    import cnn_with_pde_amd as P
+    g = torch.Generator().manual_seed(77)
+    B, C, N, steps = 48, 16, 32, 10
+    layer = quiet(P.EnhancedDiffusionLayer, N, C, num_steps=steps, channel_mixing_enabled=False)
+    _perturb(layer, g, 0.1, 0.1)
+    spec = O.AdiSpec(N, C, 0.001, 1.0, 1.0, steps, "strang", False, 10.0, "none", False)
+    params = {k: v.detach().clone() for k, v in layer.named_parameters() if k != "channel_mixing"}
+    u = torch.randn(B, C, N, N, generator=g)
+    gy = torch.randn(B, C, N, N, generator=g)
+    y_ref, gu_ref, gp_ref = CO.adi_value_and_grads(u.double(), {k: v.double() for k, v in params.items()},
+                                                   gy.double(), spec)
+    dl = layer.cuda()
+    ud = u.cuda().requires_grad_(True)
+    y = dl(ud)
+    y.backward(gy.cuda())
+    assert G.rel_err(y.detach().cpu(), y_ref) <= TOL
+    assert G.rel_err(ud.grad.cpu(), gu_ref) <= TOL
+    for k in gp_ref:
+        assert G.rel_err(getattr(dl, k).grad.cpu(), gp_ref[k]) <= TOL, k
