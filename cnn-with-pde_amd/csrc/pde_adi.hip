@@ -458,7 +458,7 @@ size_t pde_adi_forward_workspace_bytes(const PdeAdiDesc* d) {
 
 size_t pde_adi_backward_workspace_bytes(const PdeAdiDesc* d, int32_t num_checkpoints) {
     if (check_desc(d) != PDE_OK || num_checkpoints < 0) return 0;
-    const int G = groups_per_channel(d, kWaves * kJBwd, 1);
+    const int G = groups_per_channel(d, kWaves * kJBwd, 8 / kWaves);
     size_t b = coef_bytes(d) + tab_bytes() + flag_bytes(d);
     b += align_up((size_t)G * d->C * 4 * kImage * sizeof(float), 256);
     b += align_up((size_t)num_checkpoints * d->B * d->C * d->N * d->N * sizeof(float), 256);
@@ -484,7 +484,7 @@ int pde_adi_forward(const PdeAdiDesc* d, const void* u, void* y, const float* al
     SweepArgs sa{};
     sa.in0 = u; sa.out = y; sa.coef = coef; sa.tab = tab;
     sa.B = d->B; sa.C = d->C; sa.S = d->num_sweeps;
-    sa.G = groups_per_channel(d, kWaves * kJFwd, 2);
+    sa.G = groups_per_channel(d, kWaves * kJFwd, 16 / kWaves);
     sa.one_eps = 1.0f + d->eps;
     const size_t lds = (size_t)(2 * kRecFwd + kWaves * kImage) * sizeof(float);
     return dispatch_fwd(d, split_of(d), sa, sa.G * d->C, lds, st);
@@ -512,7 +512,7 @@ int pde_adi_backward(const PdeAdiDesc* d, const void* gy, const void* y, const v
     }
     if (workspace_bytes < pde_adi_backward_workspace_bytes(d, nck) || ((uintptr_t)workspace & 15)) return PDE_E_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int G = groups_per_channel(d, kWaves * kJBwd, 1);
+    const int G = groups_per_channel(d, kWaves * kJBwd, 8 / kWaves);
     char* ws = static_cast<char*>(workspace);
     float* coef = reinterpret_cast<float*>(ws);           ws += coef_bytes(d);
     SweepTab* tab = reinterpret_cast<SweepTab*>(ws);      ws += tab_bytes();
@@ -554,7 +554,7 @@ int pde_adi_backward(const PdeAdiDesc* d, const void* gy, const void* y, const v
         SweepArgs fa = sa;
         fa.in0 = u; fa.in1 = nullptr; fa.out = nullptr; fa.part = nullptr;
         fa.S = Sf;
-        fa.G = groups_per_channel(d, kWaves * kJFwd, 2);
+        fa.G = groups_per_channel(d, kWaves * kJFwd, 16 / kWaves);
         const size_t lds_f = (size_t)(2 * kRecFwd + kWaves * kImage) * sizeof(float);
         // the pre-pass stops after sweep Sf-1, which need not be a step boundary: look the axes up
         rc = dispatch_fwd(d, kSplitAny, fa, fa.G * d->C, lds_f, st, false);

@@ -8,7 +8,10 @@
 namespace pde {
 namespace {
 
-constexpr int kWaves = 8;                         // waves per workgroup (512 threads)
+#ifndef PDE_WAVES
+#define PDE_WAVES 8
+#endif
+constexpr int kWaves = PDE_WAVES;                 // waves per workgroup
 constexpr int kThreads = kWaves * 64;
 
 // Per-launch sweep table read by the sweep kernels with scalar loads (keeping it in the
@@ -65,29 +68,27 @@ constexpr int kDppWaveShr1 = 0x138;   // lane i <- lane i-1
 
 // Stage COUNT floats of a coefficient record global -> registers -> LDS: up to three 16-byte
 // pieces per thread, held in plain locals of the kernel (a struct here ends up in scratch).
-struct Staged { float4 r0, r1, r2; };
+struct Staged { float4 r0, r1, r2, r3, r4; };
 template <int COUNT>
-__device__ __forceinline__ void stage_load(const float* src, int tid, float4& r0, float4& r1, float4& r2) {
+__device__ __forceinline__ void stage_load(const float* src, int tid, Staged& st) {
     constexpr int F4 = COUNT / 4;
-    static_assert(F4 <= 3 * kThreads, "record too large for three pieces per thread");
-    r0 = reinterpret_cast<const float4*>(src)[tid];
-    if constexpr (F4 > kThreads) {
-        if (F4 >= 2 * kThreads || tid + kThreads < F4) r1 = reinterpret_cast<const float4*>(src)[tid + kThreads];
-    }
-    if constexpr (F4 > 2 * kThreads) {
-        if (tid + 2 * kThreads < F4) r2 = reinterpret_cast<const float4*>(src)[tid + 2 * kThreads];
-    }
+    static_assert(F4 <= 5 * kThreads, "record too large for five pieces per thread");
+    const float4* p = reinterpret_cast<const float4*>(src);
+    st.r0 = p[tid];
+    if constexpr (F4 > kThreads) { if (F4 >= 2 * kThreads || tid + kThreads < F4) st.r1 = p[tid + kThreads]; }
+    if constexpr (F4 > 2 * kThreads) { if (F4 >= 3 * kThreads || tid + 2 * kThreads < F4) st.r2 = p[tid + 2 * kThreads]; }
+    if constexpr (F4 > 3 * kThreads) { if (F4 >= 4 * kThreads || tid + 3 * kThreads < F4) st.r3 = p[tid + 3 * kThreads]; }
+    if constexpr (F4 > 4 * kThreads) { if (tid + 4 * kThreads < F4) st.r4 = p[tid + 4 * kThreads]; }
 }
 template <int COUNT>
-__device__ __forceinline__ void stage_store(float* dst, int tid, const float4& r0, const float4& r1, const float4& r2) {
+__device__ __forceinline__ void stage_store(float* dst, int tid, const Staged& st) {
     constexpr int F4 = COUNT / 4;
-    reinterpret_cast<float4*>(dst)[tid] = r0;
-    if constexpr (F4 > kThreads) {
-        if (F4 >= 2 * kThreads || tid + kThreads < F4) reinterpret_cast<float4*>(dst)[tid + kThreads] = r1;
-    }
-    if constexpr (F4 > 2 * kThreads) {
-        if (tid + 2 * kThreads < F4) reinterpret_cast<float4*>(dst)[tid + 2 * kThreads] = r2;
-    }
+    float4* p = reinterpret_cast<float4*>(dst);
+    p[tid] = st.r0;
+    if constexpr (F4 > kThreads) { if (F4 >= 2 * kThreads || tid + kThreads < F4) p[tid + kThreads] = st.r1; }
+    if constexpr (F4 > 2 * kThreads) { if (F4 >= 3 * kThreads || tid + 2 * kThreads < F4) p[tid + 2 * kThreads] = st.r2; }
+    if constexpr (F4 > 3 * kThreads) { if (F4 >= 4 * kThreads || tid + 3 * kThreads < F4) p[tid + 3 * kThreads] = st.r3; }
+    if constexpr (F4 > 4 * kThreads) { if (tid + 4 * kThreads < F4) p[tid + 4 * kThreads] = st.r4; }
 }
 
 // ---- plane I/O through the wave's LDS image (natural [h][w] rows, stride 36) --------
@@ -346,10 +347,11 @@ __global__ __launch_bounds__(kThreads) void adi_fwd_kernel(SweepArgs a) {
 
     // rows >= N of the wave images are never written: zero them once so idle lanes read zeros
     for (int e = tid; e < kWaves * kImage; e += kThreads) tbuf[e] = 0.f;
-    float4 st0 = make_float4(0.f, 0.f, 0.f, 0.f), st1 = st0, st2 = st0;
+    Staged stg;
+    stg.r0 = stg.r1 = stg.r2 = stg.r3 = stg.r4 = make_float4(0.f, 0.f, 0.f, 0.f);
     unsigned n = 0;                                       // running sweep counter (buffer parity)
-    stage_load<kRecFwd>(a.coef + ((size_t)0 * a.C + c) * kRecStride, tid, st0, st1, st2);
-    stage_store<kRecFwd>(cbuf, tid, st0, st1, st2);
+    stage_load<kRecFwd>(a.coef + ((size_t)0 * a.C + c) * kRecStride, tid, stg);
+    stage_store<kRecFwd>(cbuf, tid, stg);
     __syncthreads();
 
     for (int q = g; q < nchunk; q += a.G) {
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(kThreads) void adi_fwd_kernel(SweepArgs a) {
             constexpr int AX = decltype(AXC)::value;
             const int snext = (s + 1 < a.S) ? s + 1 : 0;
             const bool pre = (s + 1 < a.S) || more;
-            if (pre) stage_load<kRecFwd>(a.coef + ((size_t)snext * a.C + c) * kRecStride, tid, st0, st1, st2);
+            if (pre) stage_load<kRecFwd>(a.coef + ((size_t)snext * a.C + c) * kRecStride, tid, stg);
             const float* rec = cbuf + (n & 1) * kRecFwd;
             const int axs = (AX >= 0) ? AX : tab->axis[s];
             if (axs == PDE_AXIS_Y) {
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(kThreads) void adi_fwd_kernel(SweepArgs a) {
                 float* slot = a.ckpt + (size_t)ck_slot(a.ck, s) * a.B * a.C * plane;
                 store_planes<N, J, float>(slot, q, wave, lane, l, hf, a.B, a.C, c, T, v);
             }
-            if (pre) stage_store<kRecFwd>(cbuf + ((n + 1) & 1) * kRecFwd, tid, st0, st1, st2);
+            if (pre) stage_store<kRecFwd>(cbuf + ((n + 1) & 1) * kRecFwd, tid, stg);
             __syncthreads();
             ++n;
         };
@@ -547,10 +549,11 @@ __global__ __launch_bounds__(kThreads) void adi_bwd_kernel(SweepArgs a) {
     for (int k = 0; k < M; ++k) Ax[k] = Tx[k] = Ay[k] = Ty[k] = 0.f;
 
     for (int e = tid; e < kWaves * kImage; e += kThreads) tbuf[e] = 0.f;
-    float4 st0 = make_float4(0.f, 0.f, 0.f, 0.f), st1 = st0, st2 = st0;
+    Staged stg;
+    stg.r0 = stg.r1 = stg.r2 = stg.r3 = stg.r4 = make_float4(0.f, 0.f, 0.f, 0.f);
     unsigned n = 0;
-    stage_load<REC>(a.coef + ((size_t)(a.S - 1) * a.C + c) * kRecStride, tid, st0, st1, st2);
-    stage_store<REC>(cbuf, tid, st0, st1, st2);
+    stage_load<REC>(a.coef + ((size_t)(a.S - 1) * a.C + c) * kRecStride, tid, stg);
+    stage_store<REC>(cbuf, tid, stg);
     __syncthreads();
 
     for (int q = g; q < nchunk; q += a.G) {
@@ -566,7 +569,7 @@ __global__ __launch_bounds__(kThreads) void adi_bwd_kernel(SweepArgs a) {
             constexpr int AX = decltype(AXC)::value;
             const int snext = (s > 0) ? s - 1 : a.S - 1;
             const bool pre = (s > 0) || more;
-            if (pre) stage_load<REC>(a.coef + ((size_t)snext * a.C + c) * kRecStride, tid, st0, st1, st2);
+            if (pre) stage_load<REC>(a.coef + ((size_t)snext * a.C + c) * kRecStride, tid, stg);
             const float* rec = cbuf + (n & 1) * REC;
             const int axs = (AX >= 0) ? AX : tab->axis[s];
             float dts = tab->dts[s];
@@ -595,7 +598,7 @@ __global__ __launch_bounds__(kThreads) void adi_bwd_kernel(SweepArgs a) {
                 const float* slot = a.ckpt + (size_t)ck_slot(a.ck, s - 1) * a.B * a.C * plane;
                 load_planes<N, J, float>(slot, q, wave, lane, l, hf, a.B, a.C, c, T, x);
             }
-            if (pre) stage_store<REC>(cbuf + ((n + 1) & 1) * REC, tid, st0, st1, st2);
+            if (pre) stage_store<REC>(cbuf + ((n + 1) & 1) * REC, tid, stg);
             __syncthreads();
             ++n;
         };

@@ -9,7 +9,6 @@ struct SweepArgsOpaque;          // = SweepArgs of pde_adi_dev.h, passed by poin
 
 constexpr int kJFwd = 2;         // planes per lane in the forward kernel
 constexpr int kJBwd = 2;         // planes per lane in the backward kernel
-constexpr int kWavesPerGroup = 8;
 
 // return 0 on success, PDE_E_LAUNCH otherwise
 #define PDE_DECLARE_N(NN)                                                                              \
