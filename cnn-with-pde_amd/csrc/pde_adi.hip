@@ -30,6 +30,7 @@
 #include "pde_adi_dev.h"
 #include "pde_adi_launch.h"
 
+#include <cmath>
 #include <mutex>
 #include <type_traits>
 #include <vector>
@@ -85,6 +86,7 @@ __global__ __launch_bounds__(64) void adi_factor_kernel(FactorArgs a) {
             if (q < idx) tprev = a.sweep[q].t;
             tlast = a.sweep[q].t;
         }
+        a.tab->ysc[idx] = powf(1.0f + a.eps, -(float)(a.S - 1 - idx));
         a.tab->axis[idx] = ax;
         a.tab->dts[idx] = a.sweep[idx].t - tprev;
         a.tab->first_s[ax] = first;
@@ -97,12 +99,13 @@ __global__ __launch_bounds__(64) void adi_factor_kernel(FactorArgs a) {
     const bool live = (c < a.C) && (line < N);
     // idle lines get zero rows: lanes beyond the plane run the same instruction stream on zeros,
     // so nothing they compute can leak a NaN through a lane exchange
-    rec[kRecJn + line] = 0.f;
+    rec[kG_Jn + line] = 0.f;
     for (int i = 0; i < kLineStride; ++i) {
-        rec[kRecInv + line * kLineStride + i] = 0.f;
-        rec[kRecE + line * kLineStride + i] = 0.f;
-        rec[kRecKapX + line * kLineStride + i] = 0.f;
-        rec[kRecMaskX + line * kLineStride + i] = 0.f;
+        rec[kG_Inv + line * kLineStride + i] = 0.f;
+        rec[kG_E + line * kLineStride + i] = 0.f;
+        rec[kG_InvB + line * kLineStride + i] = 0.f;
+        rec[kG_KapX + line * kLineStride + i] = 0.f;
+        rec[kG_MaskX + line * kLineStride + i] = 0.f;
     }
     __syncthreads();
     if (live) {
@@ -147,8 +150,10 @@ __global__ __launch_bounds__(64) void adi_factor_kernel(FactorArgs a) {
             km = fmaxf(km, kap[i]);
         }
         kmax_lane = km;
-        float* inv_row = rec + kRecInv + line * kLineStride;
-        float* e_row = rec + kRecE + line * kLineStride;
+        float* inv_row = rec + kG_Inv + line * kLineStride;
+        float* invb_row = rec + kG_InvB + line * kLineStride;
+        float* e_row = rec + kG_E + line * kLineStride;
+        const float one_eps = 1.0f + a.eps;
         float e_in[2];
         // two-sided elimination of (A + eps I): rows i = k (hf 0) and i = N-1-k (hf 1),
         // den_k = b_k - kap_k * (kap_{k-1}/den_{k-1}) + eps       mnist_test.py:169,177
@@ -164,25 +169,27 @@ __global__ __launch_bounds__(64) void adi_factor_kernel(FactorArgs a) {
                 const float inv = 1.0f / den;
                 e = kp * inv;
                 inv_row[hf * kHalfPad + k] = inv;
+                invb_row[hf * kHalfPad + k] = inv * one_eps;
                 e_row[hf * kHalfPad + k] = e;
             }
             e_in[hf] = e;
         }
-        rec[kRecJn + line] = 1.0f / (1.0f - e_in[0] * e_in[1]);
+        rec[kG_Jn + line] = 1.0f / (1.0f - e_in[0] * e_in[1]);
         // coefficient and clamp mask in row layout (always): element (h,w) at row h, half_pos(w)
-        float* kx = rec + kRecKapX;
-        float* mx = rec + kRecMaskX;
+        float* kx = rec + kG_KapX;
+        float* mx = rec + kG_MaskX;
+        const float r1e = 1.0f / one_eps;
         if (xax) {
 #pragma unroll
             for (int i = 0; i < N; ++i) {
-                kx[line * kLineStride + half_pos(i, N)] = kap[i];
+                kx[line * kLineStride + half_pos(i, N)] = kap[i] * r1e;
                 mx[line * kLineStride + half_pos(i, N)] = pass[i];
             }
         } else {
             const int p = half_pos(line, N);
 #pragma unroll
             for (int i = 0; i < N; ++i) {
-                kx[i * kLineStride + p] = kap[i];
+                kx[i * kLineStride + p] = kap[i] * r1e;
                 mx[i * kLineStride + p] = pass[i];
             }
         }
@@ -539,6 +546,7 @@ int pde_adi_backward(const PdeAdiDesc* d, const void* gy, const void* y, const v
     sa.Sf = Sf; sa.smooth3 = d->smooth3;
     sa.B = d->B; sa.C = d->C; sa.S = d->num_sweeps; sa.G = G;
     sa.one_eps = 1.0f + d->eps;
+    sa.gu_scale = (float)pow(1.0 + (double)d->eps, -(double)d->num_sweeps);
     float wgt[2] = {0.f, 0.f};
     float tfirst[2] = {0.f, 0.f};
     bool have[2] = {false, false};
@@ -562,7 +570,7 @@ int pde_adi_backward(const PdeAdiDesc* d, const void* gy, const void* y, const v
     }
     const int grid = G * d->C;
     const size_t lds_fast = (size_t)(2 * kRecBwd + kWaves * kImage) * sizeof(float);
-    const size_t lds_mask = (size_t)(2 * kRecStride + kWaves * kImage) * sizeof(float);
+    const size_t lds_mask = (size_t)(2 * kRecBwdMasked + kWaves * kImage) * sizeof(float);
     // two launches over the same grid: every workgroup leaves at once unless its channel belongs
     // to the instantiation (decided on the device by the factor kernel, no host round trip)
     rc = dispatch_bwd(d, split_of(d), 0, sa, grid, lds_fast, st);
@@ -576,7 +584,8 @@ int pde_adi_backward(const PdeAdiDesc* d, const void* gy, const void* y, const v
     pa.C = d->C; pa.N = d->N; pa.S = d->num_sweeps; pa.G = G;
     pa.smooth3 = d->smooth3; pa.has_max = d->has_clamp_max; pa.accumulate = 0;
     pa.cmax = d->clamp_max; pa.eps = d->eps;
-    pa.wx = wgt[0]; pa.wy = wgt[1];
+    // the kernel's sums carry one factor (1+eps) (see pde_common.h, INVB)
+    pa.wx = wgt[0] / (1.0f + d->eps); pa.wy = wgt[1] / (1.0f + d->eps);
     pa.t_first[0] = tfirst[0]; pa.t_first[1] = tfirst[1];
     pa.have_axis[0] = have[0]; pa.have_axis[1] = have[1];
     hipLaunchKernelGGL(adi_pgrad_kernel, dim3(d->C), dim3(1024), 0, st, pa);

@@ -21,6 +21,7 @@ struct SweepTab {
     float dts[PDE_MAX_SWEEPS];      // bwd: t_s minus t of the previous (earlier) sweep of the same axis
     int first_s[2];                 // bwd: earliest sweep of each axis (-1: none)
     float t_last[2];                // bwd: time of the latest sweep of each axis
+    float ysc[PDE_MAX_SWEEPS];      // bwd: (1+eps)^-(S-1-s): true state after sweep s -> rescaled state
 };
 
 // order of the axes inside one time step, known at compile time for the two splits the
@@ -44,6 +45,7 @@ struct SweepArgs {
     int smooth3;
     int B, C, S, G;
     float one_eps;          // 1 + eps
+    float gu_scale;         // bwd: (1+eps)^-S
 };
 
 // The sweep table and the channel flags are written by an earlier kernel and only read here.
@@ -266,9 +268,9 @@ __device__ __forceinline__ void load_half(const float* src, float (&dst)[M]) {
 template <int M, int J>
 __device__ __forceinline__ void solve_fwd(float (&v)[J][M], const float* rec, int l, int hf) {
     float e[M], inv[M];
-    load_half<M>(rec + kRecE + l * kLineStride + hf * kHalfPad, e);
-    load_half<M>(rec + kRecInv + l * kLineStride + hf * kHalfPad, inv);
-    const float jn = rec[kRecJn + l];
+    load_half<M>(rec + kF_E + l * kLineStride + hf * kHalfPad, e);
+    load_half<M>(rec + kF_Inv + l * kLineStride + hf * kHalfPad, inv);
+    const float jn = rec[kF_Jn + l];
     // elimination from my end inwards: D_k = d_k*inv_k + e_k*D_{k-1}
 #pragma unroll
     for (int k = 0; k < M; ++k) {
@@ -350,7 +352,7 @@ __global__ __launch_bounds__(kThreads) void adi_fwd_kernel(SweepArgs a) {
     Staged stg;
     stg.r0 = stg.r1 = stg.r2 = stg.r3 = stg.r4 = make_float4(0.f, 0.f, 0.f, 0.f);
     unsigned n = 0;                                       // running sweep counter (buffer parity)
-    stage_load<kRecFwd>(a.coef + ((size_t)0 * a.C + c) * kRecStride, tid, stg);
+    stage_load<kRecFwd>(a.coef + ((size_t)0 * a.C + c) * kRecStride + kG_Inv, tid, stg);
     stage_store<kRecFwd>(cbuf, tid, stg);
     __syncthreads();
 
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(kThreads) void adi_fwd_kernel(SweepArgs a) {
             constexpr int AX = decltype(AXC)::value;
             const int snext = (s + 1 < a.S) ? s + 1 : 0;
             const bool pre = (s + 1 < a.S) || more;
-            if (pre) stage_load<kRecFwd>(a.coef + ((size_t)snext * a.C + c) * kRecStride, tid, stg);
+            if (pre) stage_load<kRecFwd>(a.coef + ((size_t)snext * a.C + c) * kRecStride + kG_Inv, tid, stg);
             const float* rec = cbuf + (n & 1) * kRecFwd;
             const int axs = (AX >= 0) ? AX : tab->axis[s];
             if (axs == PDE_AXIS_Y) {
@@ -404,10 +406,9 @@ __global__ __launch_bounds__(kThreads) void adi_fwd_kernel(SweepArgs a) {
 // adjoint two-sided solve (A + eps I)^T g = r on J planes, in place.
 template <int M, int J>
 __device__ __forceinline__ void solve_adj(float (&r)[J][M], const float* rec, int l, int hf) {
-    __builtin_amdgcn_sched_barrier(0);
     float e[M];
-    load_half<M>(rec + kRecE + l * kLineStride + hf * kHalfPad, e);
-    const float jn = rec[kRecJn + l];
+    load_half<M>(rec + kB_E + l * kLineStride + hf * kHalfPad, e);
+    const float jn = rec[kB_Jn + l];
     // H_k = r_k + e_{k-1} H_{k-1}
 #pragma unroll
     for (int k = 1; k < M; ++k) {
@@ -426,15 +427,13 @@ __device__ __forceinline__ void solve_adj(float (&r)[J][M], const float* rec, in
 #pragma unroll
         for (int j = 0; j < J; ++j) r[j][k] = fmaf(e[k + 1], r[j][k + 1], r[j][k]);
     }
-    __builtin_amdgcn_sched_barrier(0);
     float inv[M];
-    load_half<M>(rec + kRecInv + l * kLineStride + hf * kHalfPad, inv);
+    load_half<M>(rec + kB_Inv + l * kLineStride + hf * kHalfPad, inv);       // (1+eps)/den
 #pragma unroll
     for (int k = 0; k < M; ++k) {
 #pragma unroll
         for (int j = 0; j < J; ++j) r[j][k] *= inv[k];
     }
-    __builtin_amdgcn_sched_barrier(0);
 }
 
 // After an x sweep has been undone on the adjoint (g in r[]), use the sweep's OUTPUT state
@@ -444,22 +443,22 @@ __device__ __forceinline__ void solve_adj(float (&r)[J][M], const float* rec, in
 // masked (and un-smoothed) once at the end: do both here, per sweep.
 template <int M, int J, bool MASKED>
 __device__ __forceinline__ void state_x(const float (&g)[J][M], float (&x)[J][M], float (&acc)[M],
-                                        const float* rec, int l, int hf, float one_eps, int smooth) {
+                                        const float (&xin)[J], const float* rec, int l, int hf, int smooth) {
     float kap[M];
-    load_half<M>(rec + kRecKapX + l * kLineStride + hf * kHalfPad, kap);
+    load_half<M>(rec + kB_KapX + l * kLineStride + hf * kHalfPad, kap);
     float msk[MASKED ? M : 1];
-    if constexpr (MASKED) load_half<M>(rec + kRecMaskX + l * kLineStride + hf * kHalfPad, msk);
+    if constexpr (MASKED) load_half<M>(rec + kB_MaskX + l * kLineStride + hf * kHalfPad, msk);
 #pragma unroll
     for (int j = 0; j < J; ++j) {
         float gq[MASKED ? M : 1];
-        float xo_next = xchg_half(x[j][M - 1]);          // inner neighbour of k = M-1
+        float xo_next = xin[j];                          // inner neighbour of k = M-1 (fetched before the solve)
 #pragma unroll
         for (int k = M - 1; k >= 0; --k) {
             const float xo = x[j][k];
             float q = (k == 0) ? xo - xo_next : fmaf(2.0f, xo, -x[j][k - 1]) - xo_next;
             if constexpr (MASKED) gq[k] = g[j][k] * q;
             else acc[k] = fmaf(g[j][k], q, acc[k]);
-            x[j][k] = fmaf(kap[k], q, xo * one_eps);
+            x[j][k] = fmaf(kap[k], q, xo);
             xo_next = xo;
         }
         if constexpr (MASKED) {
@@ -484,27 +483,28 @@ __device__ __forceinline__ void state_x(const float (&g)[J][M], float (&x)[J][M]
 // same half).
 template <int N, int J, bool MASKED>
 __device__ __forceinline__ void state_y(const float (&g)[J][N / 2], float (&x)[J][N / 2], float (&acc)[N / 2],
-                                        const float* rec, int l, int hf, float one_eps, int smooth) {
+                                        const float* rec, int l, int hf, int smooth) {
     constexpr int M = N / 2;
     float kap[M];
-    load_half<M>(rec + kRecKapX + l * kLineStride + hf * kHalfPad, kap);
+    load_half<M>(rec + kB_KapX + l * kLineStride + hf * kHalfPad, kap);
     float msk[MASKED ? M : 1];
-    if constexpr (MASKED) load_half<M>(rec + kRecMaskX + l * kLineStride + hf * kHalfPad, msk);
+    if constexpr (MASKED) load_half<M>(rec + kB_MaskX + l * kLineStride + hf * kHalfPad, msk);
     const bool edge = (l == 0 || l == N - 1);
     const float kk = edge ? 1.0f : 2.0f;
     const float kz = edge ? 2.0f : 1.0f;
     const float mu = (l > 0) ? 1.0f : 0.0f;
     const float md = (l < N - 1) ? 1.0f : 0.0f;
+    const float nmu = -mu, nmd = -md;
 #pragma unroll
     for (int j = 0; j < J; ++j) {
 #pragma unroll
         for (int k = 0; k < M; ++k) {
             const float xo = x[j][k];
-            const float up = dpp_move<kDppWaveShr1>(xo);
-            const float dn = dpp_move<kDppWaveShl1>(xo);
             float q = kk * xo;
-            q = fmaf(-mu, up, q);
-            q = fmaf(-md, dn, q);
+            // q -= [h>0] x(row h-1) + [h<N-1] x(row h+1): the neighbour rows are the neighbour lanes; the
+            // DPP shift rides on the fmac (src0 = shifted x, 0 shifted in at the wave's ends)
+            asm("v_fmac_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(q) : "v"(xo), "v"(nmu));
+            asm("v_fmac_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(q) : "v"(xo), "v"(nmd));
             if constexpr (MASKED) {
                 const float gq = g[j][k] * q;
                 float z = gq;
@@ -519,7 +519,7 @@ __device__ __forceinline__ void state_y(const float (&g)[J][N / 2], float (&x)[J
             } else {
                 acc[k] = fmaf(g[j][k], q, acc[k]);
             }
-            x[j][k] = fmaf(kap[k], q, xo * one_eps);
+            x[j][k] = fmaf(kap[k], q, xo);
         }
     }
 }
@@ -527,7 +527,7 @@ __device__ __forceinline__ void state_y(const float (&g)[J][N / 2], float (&x)[J
 template <int N, int J, typename IO, bool MASKED, int SPLIT>
 __global__ __launch_bounds__(kThreads) void adi_bwd_kernel(SweepArgs a) {
     constexpr int M = Geo<N>::M;
-    constexpr int REC = MASKED ? kRecStride : kRecBwd;
+    constexpr int REC = MASKED ? kRecBwdMasked : kRecBwd;
     const int c = blockIdx.x % a.C, g = blockIdx.x / a.C;
     if ((as_const(a.varying)[c] != 0) != MASKED) return;  // the other instantiation owns this channel
     const ConstTab tab = as_const(a.tab);
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(kThreads) void adi_bwd_kernel(SweepArgs a) {
     Staged stg;
     stg.r0 = stg.r1 = stg.r2 = stg.r3 = stg.r4 = make_float4(0.f, 0.f, 0.f, 0.f);
     unsigned n = 0;
-    stage_load<REC>(a.coef + ((size_t)(a.S - 1) * a.C + c) * kRecStride, tid, stg);
+    stage_load<REC>(a.coef + ((size_t)(a.S - 1) * a.C + c) * kRecStride + kBwdOff, tid, stg);
     stage_store<REC>(cbuf, tid, stg);
     __syncthreads();
 
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(kThreads) void adi_bwd_kernel(SweepArgs a) {
             constexpr int AX = decltype(AXC)::value;
             const int snext = (s > 0) ? s - 1 : a.S - 1;
             const bool pre = (s > 0) || more;
-            if (pre) stage_load<REC>(a.coef + ((size_t)snext * a.C + c) * kRecStride, tid, stg);
+            if (pre) stage_load<REC>(a.coef + ((size_t)snext * a.C + c) * kRecStride + kBwdOff, tid, stg);
             const float* rec = cbuf + (n & 1) * REC;
             const int axs = (AX >= 0) ? AX : tab->axis[s];
             float dts = tab->dts[s];
@@ -580,14 +580,17 @@ __global__ __launch_bounds__(kThreads) void adi_bwd_kernel(SweepArgs a) {
                 solve_adj<M, J>(r, rec, l, hf);
 #pragma unroll
                 for (int j = 0; j < J; ++j) relayout<N>(r[j], T, l, hf);
-                state_y<N, J, MASKED>(r, x, Ay, rec, l, hf, a.one_eps, a.smooth3);
+                state_y<N, J, MASKED>(r, x, Ay, rec, l, hf, a.smooth3);
                 if (dts != 0.f) {
 #pragma unroll
                     for (int k = 0; k < M; ++k) Ty[k] = fmaf(dts, Ay[k], Ty[k]);
                 }
             } else {
+                float xin[J];                             // partner half's innermost state: issue the
+#pragma unroll
+                for (int j = 0; j < J; ++j) xin[j] = xchg_half(x[j][M - 1]);   // exchange now, use it after the solve
                 solve_adj<M, J>(r, rec, l, hf);
-                state_x<M, J, MASKED>(r, x, Ax, rec, l, hf, a.one_eps, a.smooth3);
+                state_x<M, J, MASKED>(r, x, Ax, xin, rec, l, hf, a.smooth3);
                 if (dts != 0.f) {
 #pragma unroll
                     for (int k = 0; k < M; ++k) Tx[k] = fmaf(dts, Ax[k], Tx[k]);
@@ -597,6 +600,12 @@ __global__ __launch_bounds__(kThreads) void adi_bwd_kernel(SweepArgs a) {
             if (s > 0 && a.ckpt != nullptr && ck_bit(a.ck, s - 1)) {
                 const float* slot = a.ckpt + (size_t)ck_slot(a.ck, s - 1) * a.B * a.C * plane;
                 load_planes<N, J, float>(slot, q, wave, lane, l, hf, a.B, a.C, c, T, x);
+                const float sc = tab->ysc[s - 1];             // true state -> rescaled state of sweep s-1
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+#pragma unroll
+                    for (int k = 0; k < M; ++k) x[j][k] *= sc;
+                }
             }
             if (pre) stage_store<REC>(cbuf + ((n + 1) & 1) * REC, tid, stg);
             __syncthreads();
@@ -615,6 +624,11 @@ __global__ __launch_bounds__(kThreads) void adi_bwd_kernel(SweepArgs a) {
             }
         } else {
             for (int s = a.S - 1; s >= 0; --s) sweep(std::integral_constant<int, -1>{}, s);
+        }
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+#pragma unroll
+            for (int k = 0; k < M; ++k) r[j][k] *= a.gu_scale;     // undo the (1+eps) carried per sweep
         }
         store_planes<N, J, IO>(gu, q, wave, lane, l, hf, a.B, a.C, c, T, r);
     }

@@ -16,18 +16,33 @@ constexpr int kLineStride = 36;
 constexpr int kImage = 32 * kLineStride;            // 1152 floats = 4608 B
 constexpr int kHalfPad = 16;
 
-// Coefficient record of one (sweep, channel), exactly as it sits in LDS:
-//   [JN 32][INV image][E image][KAPX image][MASKX image]
-// INV/E are indexed by the sweep's own lines; KAPX (the coefficient itself) and MASKX (1 where
-// the clamp lets the gradient through, else 0) always by rows (x layout).
-constexpr int kRecJn = 0;
-constexpr int kRecInv = 32;
-constexpr int kRecE = 32 + kImage;
-constexpr int kRecKapX = 32 + 2 * kImage;
-constexpr int kRecMaskX = 32 + 3 * kImage;
-constexpr int kRecFwd = 32 + 2 * kImage;            // floats staged by the forward
-constexpr int kRecBwd = 32 + 3 * kImage;            // floats staged by the backward (constant masks)
-constexpr int kRecStride = 32 + 4 * kImage;         // record stride in global memory; staged whole by the masked backward
+// Coefficient record of one (sweep, channel) in global memory, stored exactly as it sits in LDS:
+//   [INV image][JN 32][E image][INVB image][KAPX image][MASKX image]
+// INV, E, INVB are indexed by the sweep's own lines; KAPX and MASKX always by rows (x layout).
+//   INV   1/den of the two-sided factorisation            (forward)
+//   JN    1/(1 - e_t e_b), the junction factor per line   (forward, backward)
+//   E     kap/den                                          (forward, backward)
+//   INVB  (1+eps)/den: the adjoint solve carries one factor (1+eps) per sweep so that the state
+//         can be rebuilt with ONE fma, y_{s-1} = y_s + KAPX (L y_s), on the rescaled state
+//         y_s = x_s (1+eps)^-(S-1-s)        (backward)
+//   KAPX  kap/(1+eps)                                      (backward)
+//   MASKX 1 where the clamp lets the gradient through      (masked backward only)
+// The forward stages the prefix [INV|JN|E]; the backward the suffix starting at JN.
+constexpr int kG_Inv = 0;
+constexpr int kG_Jn = kImage;
+constexpr int kG_E = kImage + 32;
+constexpr int kG_InvB = 2 * kImage + 32;
+constexpr int kG_KapX = 3 * kImage + 32;
+constexpr int kG_MaskX = 4 * kImage + 32;
+constexpr int kRecStride = 5 * kImage + 32;          // record stride in global memory (floats)
+// forward view (staged from kG_Inv)
+constexpr int kRecFwd = 2 * kImage + 32;
+constexpr int kF_Inv = 0, kF_Jn = kImage, kF_E = kImage + 32;
+// backward view (staged from kG_Jn)
+constexpr int kBwdOff = kG_Jn;
+constexpr int kRecBwd = 3 * kImage + 32;             // JN, E, INVB, KAPX
+constexpr int kRecBwdMasked = 4 * kImage + 32;       // ... + MASKX
+constexpr int kB_Jn = 0, kB_E = 32, kB_Inv = kImage + 32, kB_KapX = 2 * kImage + 32, kB_MaskX = 3 * kImage + 32;
 
 // position of global index j inside a line image row
 __host__ __device__ inline int half_pos(int j, int N) { return (j < N / 2) ? j : kHalfPad + (N - 1 - j); }
