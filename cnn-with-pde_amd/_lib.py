@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libpdecnn_hip.so")
+# PDECNN_LIB: developer override (timing-only ablation builds of tools/ablate.sh)
+LIB_PATH = os.environ.get("PDECNN_LIB") or os.path.join(HERE, "lib", "libpdecnn_hip.so")
 
 PDE_MAX_SWEEPS = 96
 PDE_MAX_N = 32

@@ -31,6 +31,7 @@
 #include "pde_adi_launch.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <mutex>
 #include <type_traits>
 #include <vector>
@@ -63,17 +64,37 @@ struct FactorArgs {
     PdeSweep sweep[PDE_MAX_SWEEPS];
 };
 
+// One thread per (sweep, channel, line): it factorises its own line (two-sided) and writes its row of
+// every image of the record as nine 16-byte stores.  No LDS, so occupancy is not limited and a
+// 64-thread block (two channels of one sweep) costs nothing to schedule.  The row-layout images
+// (KAPX, MASKX) of a y sweep are NOT transposed through memory: thread h recomputes the
+// coefficient of row h directly from the parameters (three rows for the smoothed variants).
+template <int N>
+__device__ __forceinline__ void store_row(float* dst, const float (&lo)[N / 2], const float (&hi)[N / 2]) {
+    // image row = [16 floats: half seen from the low end][16: half seen from the high end][4 pad]
+    float row[kLineStride];
+#pragma unroll
+    for (int p = 0; p < kLineStride; ++p) row[p] = 0.f;
+#pragma unroll
+    for (int k = 0; k < N / 2; ++k) { row[k] = lo[k]; row[kHalfPad + k] = hi[k]; }
+#pragma unroll
+    for (int q = 0; q < kLineStride / 4; ++q)
+        reinterpret_cast<float4*>(dst)[q] = make_float4(row[4 * q], row[4 * q + 1], row[4 * q + 2], row[4 * q + 3]);
+}
+
+__device__ __forceinline__ float clamp_theta(float th, const FactorArgs& a, bool& pass) {
+    pass = (th >= a.eps) && (!a.has_max || th <= a.cmax);                  // clamp passes the gradient
+    th = fmaxf(th, a.eps);
+    if (a.has_max) th = fminf(th, a.cmax);
+    return th;
+}
+
 template <int N>
 __global__ __launch_bounds__(64) void adi_factor_kernel(FactorArgs a) {
-    // one wave = two records (sweep s, channels 2p and 2p+1); lane = (record, line).  Records are
-    // built in LDS and written out as whole 16-byte rows: a line-per-thread store straight to
-    // global memory is a 4-byte scatter and ran 10x slower.
-    __shared__ __attribute__((aligned(16))) float rec_s[2][kRecStride];
     constexpr int m = N / 2;
     const int pairs = (a.C + 1) / 2;
     const int s = blockIdx.x / pairs;
-    const int which = threadIdx.x >> 5;
-    const int c = 2 * (blockIdx.x % pairs) + which;
+    const int c = 2 * (blockIdx.x % pairs) + (threadIdx.x >> 5);
     const int line = threadIdx.x & 31;
     if (blockIdx.x == 0 && threadIdx.x < a.S) {   // publish the sweep table
         const int idx = threadIdx.x;
@@ -92,119 +113,117 @@ __global__ __launch_bounds__(64) void adi_factor_kernel(FactorArgs a) {
         a.tab->first_s[ax] = first;
         a.tab->t_last[ax] = tlast;
     }
-    float* rec = rec_s[which];
     float kmax_lane = 0.f;
     const PdeSweep sw = a.sweep[s];
     const bool xax = sw.axis == PDE_AXIS_X;
-    const bool live = (c < a.C) && (line < N);
-    // idle lines get zero rows: lanes beyond the plane run the same instruction stream on zeros,
-    // so nothing they compute can leak a NaN through a lane exchange
-    rec[kG_Jn + line] = 0.f;
-    for (int i = 0; i < kLineStride; ++i) {
-        rec[kG_Inv + line * kLineStride + i] = 0.f;
-        rec[kG_E + line * kLineStride + i] = 0.f;
-        rec[kG_InvB + line * kLineStride + i] = 0.f;
-        rec[kG_KapX + line * kLineStride + i] = 0.f;
-        rec[kG_MaskX + line * kLineStride + i] = 0.f;
-    }
-    __syncthreads();
-    if (live) {
-        const float* base = xax ? a.ab : a.bb;
-        const float* slope = xax ? a.as : a.bs;
-        const size_t cbase = (size_t)c * N * N;
-        const int st = xax ? 1 : N;                 // stride between consecutive unknowns of my line
-        const int o0 = xax ? line * N : line;
-        float kap[N];
-        float pass[N];
-        bool differs = false;
-        // theta = clamp(base + slope*t, eps[, max])          mnist_test.py:33-42
+    if (c < a.C) {
+        float* rec = a.coef + ((size_t)s * a.C + c) * kRecStride;
+        float zero[m];
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-            const float bs = base[cbase + o0 + i * st], sl = slope[cbase + o0 + i * st];
-            float th = bs + sl * sw.t;
-            const bool ps = (th >= a.eps) && (!a.has_max || th <= a.cmax);     // clamp passes the gradient
-            const float th0 = bs + sl * a.t_first[sw.axis];
-            const bool ps0 = (th0 >= a.eps) && (!a.has_max || th0 <= a.cmax);
-            differs |= (ps != ps0);
-            pass[i] = ps ? 1.0f : 0.0f;
-            th = fmaxf(th, a.eps);
-            if (a.has_max) th = fminf(th, a.cmax);
-            kap[i] = th;
-        }
-        if (differs && a.varying) atomicOr(&a.varying[c], 1);
-        if (a.smooth3) {                             // mnist_test.py:135-149 (replicate ends)
-            const float third = 1.0f / 3.0f;
-            float prev = kap[0];
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-                const float cur = kap[i];
-                const float nxt = kap[i + 1 < N ? i + 1 : N - 1];
-                kap[i] = (prev * third + cur * third) + nxt * third;
-                prev = cur;
-            }
-        }
-        float km = 0.f;
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            kap[i] = (kap[i] * sw.delta) / sw.h2;     // coeff = theta*dt/dx**2  mnist_test.py:83
-            km = fmaxf(km, kap[i]);
-        }
-        kmax_lane = km;
-        float* inv_row = rec + kG_Inv + line * kLineStride;
-        float* invb_row = rec + kG_InvB + line * kLineStride;
-        float* e_row = rec + kG_E + line * kLineStride;
-        const float one_eps = 1.0f + a.eps;
-        float e_in[2];
-        // two-sided elimination of (A + eps I): rows i = k (hf 0) and i = N-1-k (hf 1),
-        // den_k = b_k - kap_k * (kap_{k-1}/den_{k-1}) + eps       mnist_test.py:169,177
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            float e = 0.f;                           // kap_{k-1}/den_{k-1} of the outer neighbour
-#pragma unroll
-            for (int k = 0; k < m; ++k) {
-                const int i = hf ? N - 1 - k : k;
-                const float kp = kap[i];
-                const float b = (k == 0) ? 1.0f + kp : 1.0f + 2.0f * kp;    // Neumann ends, mnist_test.py:88-93
-                const float den = (b - kp * e) + a.eps;
-                const float inv = 1.0f / den;
-                e = kp * inv;
-                inv_row[hf * kHalfPad + k] = inv;
-                invb_row[hf * kHalfPad + k] = inv * one_eps;
-                e_row[hf * kHalfPad + k] = e;
-            }
-            e_in[hf] = e;
-        }
-        rec[kG_Jn + line] = 1.0f / (1.0f - e_in[0] * e_in[1]);
-        // coefficient and clamp mask in row layout (always): element (h,w) at row h, half_pos(w)
-        float* kx = rec + kG_KapX;
-        float* mx = rec + kG_MaskX;
-        const float r1e = 1.0f / one_eps;
-        if (xax) {
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-                kx[line * kLineStride + half_pos(i, N)] = kap[i] * r1e;
-                mx[line * kLineStride + half_pos(i, N)] = pass[i];
-            }
+        for (int k = 0; k < m; ++k) zero[k] = 0.f;
+        if (line >= N) {
+            // idle lines get zero rows: lanes beyond the plane run the same instruction stream on
+            // zeros, so nothing they compute can leak a NaN through a lane exchange
+            rec[kG_Jn + line] = 0.f;
+            store_row<N>(rec + kG_Inv + line * kLineStride, zero, zero);
+            store_row<N>(rec + kG_E + line * kLineStride, zero, zero);
+            store_row<N>(rec + kG_InvB + line * kLineStride, zero, zero);
+            store_row<N>(rec + kG_KapX + line * kLineStride, zero, zero);
+            store_row<N>(rec + kG_MaskX + line * kLineStride, zero, zero);
         } else {
-            const int p = half_pos(line, N);
+            const float* base = xax ? a.ab : a.bb;
+            const float* slope = xax ? a.as : a.bs;
+            const size_t cbase = (size_t)c * N * N;
+            const int st = xax ? 1 : N;                 // stride between consecutive unknowns of my line
+            const int o0 = xax ? line * N : line;
+            const float third = 1.0f / 3.0f;
+            const float one_eps = 1.0f + a.eps, r1e = 1.0f / one_eps;
+            float kap[N];
+            float pass[N];
+            bool differs = false;
+            // theta = clamp(base + slope*t, eps[, max])          mnist_test.py:33-42
 #pragma unroll
             for (int i = 0; i < N; ++i) {
-                kx[i * kLineStride + p] = kap[i] * r1e;
-                mx[i * kLineStride + p] = pass[i];
+                const float bs = base[cbase + o0 + i * st], sl = slope[cbase + o0 + i * st];
+                bool ps, ps0;
+                kap[i] = clamp_theta(bs + sl * sw.t, a, ps);
+                (void)clamp_theta(bs + sl * a.t_first[sw.axis], a, ps0);
+                differs |= (ps != ps0);
+                pass[i] = ps ? 1.0f : 0.0f;
             }
+            if (differs && a.varying) atomicOr(&a.varying[c], 1);
+            if (a.smooth3) {                             // mnist_test.py:135-149 (replicate ends)
+                float prev = kap[0];
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    const float cur = kap[i];
+                    const float nxt = kap[i + 1 < N ? i + 1 : N - 1];
+                    kap[i] = (prev * third + cur * third) + nxt * third;
+                    prev = cur;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                kap[i] = (kap[i] * sw.delta) / sw.h2;     // coeff = theta*dt/dx**2  mnist_test.py:83
+                kmax_lane = fmaxf(kmax_lane, kap[i]);
+            }
+            // two-sided elimination of (A + eps I): rows i = k (hf 0) and i = N-1-k (hf 1),
+            // den_k = b_k - kap_k * (kap_{k-1}/den_{k-1}) + eps       mnist_test.py:169,177
+            float inv[2][m], ee[2][m], invb[2][m];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                float e = 0.f;                           // kap_{k-1}/den_{k-1} of the outer neighbour
+#pragma unroll
+                for (int k = 0; k < m; ++k) {
+                    const int i = hf ? N - 1 - k : k;
+                    const float kp = kap[i];
+                    const float b = (k == 0) ? 1.0f + kp : 1.0f + 2.0f * kp;    // Neumann ends, mnist_test.py:88-93
+                    const float den = (b - kp * e) + a.eps;
+                    const float iv = 1.0f / den;
+                    e = kp * iv;
+                    inv[hf][k] = iv;
+                    invb[hf][k] = iv * one_eps;
+                    ee[hf][k] = e;
+                }
+            }
+            rec[kG_Jn + line] = 1.0f / (1.0f - ee[0][m - 1] * ee[1][m - 1]);
+            store_row<N>(rec + kG_Inv + line * kLineStride, inv[0], inv[1]);
+            store_row<N>(rec + kG_E + line * kLineStride, ee[0], ee[1]);
+            store_row<N>(rec + kG_InvB + line * kLineStride, invb[0], invb[1]);
+            // coefficient and clamp mask in ROW layout: row h = line, element (h,w) at half_pos(w)
+            float kx[2][m], mx[2][m];
+            if (xax) {
+#pragma unroll
+                for (int k = 0; k < m; ++k) {
+                    kx[0][k] = kap[k] * r1e;           mx[0][k] = pass[k];
+                    kx[1][k] = kap[N - 1 - k] * r1e;   mx[1][k] = pass[N - 1 - k];
+                }
+            } else {
+                // y sweep: coefficient of row h = line along w, from beta directly (smoothing runs along h)
+                const int h = line;
+                const int hm = h > 0 ? h - 1 : 0, hp = h + 1 < N ? h + 1 : N - 1;
+#pragma unroll
+                for (int w = 0; w < N; ++w) {
+                    bool ps, pd;
+                    float th = clamp_theta(base[cbase + h * N + w] + slope[cbase + h * N + w] * sw.t, a, ps);
+                    if (a.smooth3) {
+                        const float tm = clamp_theta(base[cbase + hm * N + w] + slope[cbase + hm * N + w] * sw.t, a, pd);
+                        const float tp = clamp_theta(base[cbase + hp * N + w] + slope[cbase + hp * N + w] * sw.t, a, pd);
+                        th = (tm * third + th * third) + tp * third;
+                    }
+                    const float kv = ((th * sw.delta) / sw.h2) * r1e;
+                    const int hf = w < m ? 0 : 1, k = w < m ? w : N - 1 - w;
+                    kx[hf][k] = kv;
+                    mx[hf][k] = ps ? 1.0f : 0.0f;
+                }
+            }
+            store_row<N>(rec + kG_KapX + line * kLineStride, kx[0], kx[1]);
+            store_row<N>(rec + kG_MaskX + line * kLineStride, mx[0], mx[1]);
         }
     }
     if (a.kmax) {                                    // per-sweep maximum coefficient: one atomic per wave
         for (int o = 32; o > 0; o >>= 1) kmax_lane = fmaxf(kmax_lane, __shfl_xor(kmax_lane, o, 64));
         if (threadIdx.x == 0) atomicMax((unsigned int*)&a.kmax[s], __float_as_uint(kmax_lane));   // values are > 0
-    }
-    __syncthreads();
-    for (int w = 0; w < 2; ++w) {
-        const int cw = 2 * (blockIdx.x % pairs) + w;
-        if (cw >= a.C) break;
-        float4* dst = reinterpret_cast<float4*>(a.coef + ((size_t)s * a.C + cw) * kRecStride);
-        const float4* src = reinterpret_cast<const float4*>(rec_s[w]);
-        for (int f = threadIdx.x; f < kRecStride / 4; f += 64) dst[f] = src[f];
     }
 }
 
@@ -345,9 +364,18 @@ size_t tab_bytes() { return align_up(sizeof(SweepTab), 256); }
 size_t flag_bytes(const PdeAdiDesc* d) { return align_up((size_t)d->C * sizeof(int), 256); }
 
 
+// Workgroups per channel.  With C a multiple of 8 the XCD-ordered map is used and a channel gets one
+// XCD's worth of workgroups (32 CUs x wg_per_cu) when the batch has that many chunks; otherwise
+// just enough groups to fill the chip once.
+int env_int(const char* name, int dflt) {           // developer tuning knobs (tools/, never needed in production)
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+bool use_xcd_map(const PdeAdiDesc* d) { return (d->C % 8) == 0 && env_int("PDE_XCD", 1) != 0; }
 int groups_per_channel(const PdeAdiDesc* d, int planes_per_iter, int wg_per_cu) {
     const int nchunk = (d->B + planes_per_iter - 1) / planes_per_iter;
-    int G = (256 * wg_per_cu + d->C - 1) / d->C;           // fill the chip once
+    int G = use_xcd_map(d) ? 32 * wg_per_cu : (256 * wg_per_cu + d->C - 1) / d->C;
+    G = env_int(wg_per_cu == 8 / kWaves ? "PDE_G_BWD" : "PDE_G_FWD", G);
     if (G < 1) G = 1;
     if (G > nchunk) G = nchunk;
     return G;
@@ -467,7 +495,7 @@ size_t pde_adi_backward_workspace_bytes(const PdeAdiDesc* d, int32_t num_checkpo
     if (check_desc(d) != PDE_OK || num_checkpoints < 0) return 0;
     const int G = groups_per_channel(d, kWaves * kJBwd, 8 / kWaves);
     size_t b = coef_bytes(d) + tab_bytes() + flag_bytes(d);
-    b += align_up((size_t)G * d->C * 4 * kImage * sizeof(float), 256);
+    b += align_up((size_t)G * d->C * 4 * kImage * sizeof(float), 256) + 512;     // + diagnostics scratch
     b += align_up((size_t)num_checkpoints * d->B * d->C * d->N * d->N * sizeof(float), 256);
     return b;
 }
@@ -493,6 +521,7 @@ int pde_adi_forward(const PdeAdiDesc* d, const void* u, void* y, const float* al
     sa.B = d->B; sa.C = d->C; sa.S = d->num_sweeps;
     sa.G = groups_per_channel(d, kWaves * kJFwd, 16 / kWaves);
     sa.one_eps = 1.0f + d->eps;
+    sa.xcd_map = use_xcd_map(d);
     const size_t lds = (size_t)(2 * kRecFwd + kWaves * kImage) * sizeof(float);
     return dispatch_fwd(d, split_of(d), sa, sa.G * d->C, lds, st);
 }
@@ -525,6 +554,7 @@ int pde_adi_backward(const PdeAdiDesc* d, const void* gy, const void* y, const v
     SweepTab* tab = reinterpret_cast<SweepTab*>(ws);      ws += tab_bytes();
     int* varying = reinterpret_cast<int*>(ws);            ws += flag_bytes(d);
     float* part = reinterpret_cast<float*>(ws);           ws += align_up((size_t)G * d->C * 4 * kImage * sizeof(float), 256);
+    void* dbg = ws;                                       ws += 512;
     float* ckpt = reinterpret_cast<float*>(ws);
     if (fwd_workspace) {
         // the forward call of the same step left the factorisation, the sweep table and the
@@ -544,9 +574,11 @@ int pde_adi_backward(const PdeAdiDesc* d, const void* gy, const void* y, const v
     sa.varying = varying; sa.ckpt = ckpt;
     sa.ck[0] = nck ? ckpt_mask[0] : 0ull; sa.ck[1] = nck ? ckpt_mask[1] : 0ull;
     sa.Sf = Sf; sa.smooth3 = d->smooth3;
+    sa.xcd_map = use_xcd_map(d);
     sa.B = d->B; sa.C = d->C; sa.S = d->num_sweeps; sa.G = G;
     sa.one_eps = 1.0f + d->eps;
     sa.gu_scale = (float)pow(1.0 + (double)d->eps, -(double)d->num_sweeps);
+    sa.dbg = dbg;
     float wgt[2] = {0.f, 0.f};
     float tfirst[2] = {0.f, 0.f};
     bool have[2] = {false, false};

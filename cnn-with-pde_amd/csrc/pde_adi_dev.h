@@ -43,9 +43,11 @@ struct SweepArgs {
     unsigned long long ck[2];   // bit s: the state after sweep s is checkpointed
     int Sf;                 // bwd: sweeps 0..Sf-1 are recomputed forward first (0: no checkpoints)
     int smooth3;
+    int xcd_map;            // 1: XCD-ordered block -> (channel, group) map (needs C % 8 == 0)
     int B, C, S, G;
     float one_eps;          // 1 + eps
     float gu_scale;         // bwd: (1+eps)^-S
+    void* dbg;              // diagnostic builds only
 };
 
 // The sweep table and the channel flags are written by an earlier kernel and only read here.
@@ -56,6 +58,49 @@ typedef const __attribute__((address_space(4))) SweepTab* ConstTab;
 typedef const __attribute__((address_space(4))) int* ConstInt;
 __device__ __forceinline__ ConstTab as_const(const SweepTab* p) { return (ConstTab)(unsigned long long)p; }
 __device__ __forceinline__ ConstInt as_const(const int* p) { return (ConstInt)(unsigned long long)p; }
+
+// blockIdx -> (channel, group).  Workgroups are observed to be dealt round-robin over the 8 XCDs
+// (MI355X_MICROARCH.md, "Workgroup dispatch"), each with a private 4 MB L2.  With xcd_map the G
+// groups of one channel are consecutive on ONE XCD, so an XCD walks through its channels one (or
+// two) at a time and the channel's coefficient records (S x 14 KB) stay L2-resident instead of
+// eight channels' worth competing with the streamed tensors.  Placement affects speed only.
+__device__ __forceinline__ void block_to_work(int b, int C, int G, int xcd_map, int& c, int& g) {
+    if (xcd_map) {
+        const int x = b & 7, j = b >> 3;
+        c = x + 8 * (j / G);
+        g = j % G;
+    } else {
+        c = b % C;
+        g = b / C;
+    }
+}
+
+// 16 bytes per lane, global -> LDS without passing through registers (LDS address = wave-uniform
+// base + 16*lane).  Issued from inline asm ON PURPOSE: with the builtin, hipcc treats the DMA as a
+// pending LDS store and puts s_waitcnt vmcnt(0) in front of the next ds_read of ANY address, i.e. it
+// waits out the full memory latency right after issuing the prefetch.  The asm form is invisible to
+// that pass, so the kernel waits itself: dma_wait_all() before the barrier that publishes the data.
+// (m0 is not used by anything else in these kernels; gfx9 DS instructions do not need it.)
+__device__ __forceinline__ void lds_dma16(const float* gsrc, float* lds_wave_base) {
+    const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds_wave_base;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds), "v"(gsrc) : "memory");
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+#ifdef PDE_STAMP
+// Diagnostic build only (tools/stamp.sh): cycle stamps of one wave's phases inside a sweep.  The
+// values go to a debug buffer nothing else reads; no shipped kernel executes a stamp.
+__device__ __forceinline__ unsigned long long stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define PDE_STAMP_AT(i) do { if (stamp_on) stamps[i] = stamp(); } while (0)
+#else
+#define PDE_STAMP_AT(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ float xchg_half(float v) {     // value held by lane ^ 32
     return __shfl_xor(v, 32, 64);
@@ -232,6 +277,9 @@ __device__ __forceinline__ void rows_to_plane(const float (&v)[Geo<N>::M], float
 template <int N>
 __device__ __forceinline__ void relayout(float (&v)[Geo<N>::M], float* T, int l, int hf) {
     constexpr int M = Geo<N>::M;
+#if defined(PDE_ABL) && PDE_ABL == 1
+    return;                                   // ablation: no re-layout (results wrong, timing only)
+#endif
     if (l < N) {
         const int mypos = (l < M) ? l : kHalfPad + (N - 1 - l);
         float* dst = T + hf * M * kLineStride + mypos;
@@ -338,7 +386,8 @@ __global__ __launch_bounds__(kThreads) void adi_fwd_kernel(SweepArgs a) {
     float* tbuf = smem + 2 * kRecFwd;                     // [kWaves][kImage]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hf = lane >> 5, l = lane & 31;
-    const int c = blockIdx.x % a.C, g = blockIdx.x / a.C;
+    int c, g;
+    block_to_work(blockIdx.x, a.C, a.G, a.xcd_map, c, g);
     float* T = tbuf + wave * kImage;
     const IO* u = static_cast<const IO*>(a.in0);
     IO* y = static_cast<IO*>(a.out);
@@ -364,7 +413,9 @@ __global__ __launch_bounds__(kThreads) void adi_fwd_kernel(SweepArgs a) {
             constexpr int AX = decltype(AXC)::value;
             const int snext = (s + 1 < a.S) ? s + 1 : 0;
             const bool pre = (s + 1 < a.S) || more;
+#if !(defined(PDE_ABL) && PDE_ABL == 3)
             if (pre) stage_load<kRecFwd>(a.coef + ((size_t)snext * a.C + c) * kRecStride + kG_Inv, tid, stg);
+#endif
             const float* rec = cbuf + (n & 1) * kRecFwd;
             const int axs = (AX >= 0) ? AX : tab->axis[s];
             if (axs == PDE_AXIS_Y) {
@@ -380,9 +431,11 @@ __global__ __launch_bounds__(kThreads) void adi_fwd_kernel(SweepArgs a) {
                 float* slot = a.ckpt + (size_t)ck_slot(a.ck, s) * a.B * a.C * plane;
                 store_planes<N, J, float>(slot, q, wave, lane, l, hf, a.B, a.C, c, T, v);
             }
+#if !(defined(PDE_ABL) && PDE_ABL == 3)
             if (pre) stage_store<kRecFwd>(cbuf + ((n + 1) & 1) * kRecFwd, tid, stg);
             __syncthreads();
             ++n;
+#endif
         };
         if constexpr (SPLIT == kSplitStrang) {
             for (int s = 0; s < a.S; s += 3) {
@@ -524,16 +577,31 @@ __device__ __forceinline__ void state_y(const float (&g)[J][N / 2], float (&x)[J
     }
 }
 
+// LDS footprint (floats) of the coefficient buffers of the backward kernel.  With a compile-time
+// step pattern the records of a WHOLE STEP are staged at once by LDS-DMA (global_load_lds, no
+// registers, no ds_write) into one of two step buffers, and the workgroup meets at ONE barrier per
+// step instead of one per sweep; records are padded to whole 1-KB DMA pieces.
+template <bool MASKED, int SPLIT>
+struct BwdStage {
+    static constexpr int kSps = SPLIT == kSplitStrang ? 3 : (SPLIT == kSplitLie ? 2 : 1);
+    static constexpr bool kStep = SPLIT != kSplitAny;
+    static constexpr int kRec = MASKED ? kRecBwdMasked : kRecBwd;
+    static constexpr int kRecPad = kStep ? ((kRec / 4 + 63) / 64) * 256 : kRec;
+    static constexpr int kFloats = 2 * kSps * kRecPad;
+};
+
 template <int N, int J, typename IO, bool MASKED, int SPLIT>
 __global__ __launch_bounds__(kThreads) void adi_bwd_kernel(SweepArgs a) {
     constexpr int M = Geo<N>::M;
-    constexpr int REC = MASKED ? kRecBwdMasked : kRecBwd;
-    const int c = blockIdx.x % a.C, g = blockIdx.x / a.C;
+    using ST = BwdStage<MASKED, SPLIT>;
+    constexpr int REC = ST::kRec, RECP = ST::kRecPad, SPS = ST::kSps;
+    int c, g;
+    block_to_work(blockIdx.x, a.C, a.G, a.xcd_map, c, g);
     if ((as_const(a.varying)[c] != 0) != MASKED) return;  // the other instantiation owns this channel
     const ConstTab tab = as_const(a.tab);
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* cbuf = smem;                                   // [2][REC]
-    float* tbuf = smem + 2 * REC;                         // [kWaves][kImage]
+    float* cbuf = smem;                                   // [2][SPS][RECP]
+    float* tbuf = smem + ST::kFloats;                     // [kWaves][kImage]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hf = lane >> 5, l = lane & 31;
     float* T = tbuf + wave * kImage;
@@ -549,11 +617,28 @@ __global__ __launch_bounds__(kThreads) void adi_bwd_kernel(SweepArgs a) {
     for (int k = 0; k < M; ++k) Ax[k] = Tx[k] = Ay[k] = Ty[k] = 0.f;
 
     for (int e = tid; e < kWaves * kImage; e += kThreads) tbuf[e] = 0.f;
+
+    // records of the step whose newest sweep is s_hi -> step buffer `buf` (slot r holds sweep s_hi - r)
+    auto dma_step = [&](int buf, int s_hi) {
+        constexpr int PPR = RECP / 256;                   // 1-KB pieces per record
+        for (int p = wave; p < SPS * PPR; p += kWaves) {
+            const int rr = p / PPR, pp = p % PPR;
+            const int f = pp * 64 + lane;                 // 16-byte index inside the record
+            const float* src = a.coef + ((size_t)(s_hi - rr) * a.C + c) * kRecStride + kBwdOff + 4 * f;
+            float* dst = cbuf + ((size_t)buf * SPS + rr) * RECP + pp * 256;          // wave-uniform
+            if (f < REC / 4) lds_dma16(src, dst);
+        }
+    };
     Staged stg;
     stg.r0 = stg.r1 = stg.r2 = stg.r3 = stg.r4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    unsigned n = 0;
-    stage_load<REC>(a.coef + ((size_t)(a.S - 1) * a.C + c) * kRecStride + kBwdOff, tid, stg);
-    stage_store<REC>(cbuf, tid, stg);
+    unsigned n = 0;                                       // buffer parity (per step or per sweep)
+    if constexpr (ST::kStep) {
+        dma_step(0, a.S - 1);
+        dma_wait_all();
+    } else {
+        stage_load<REC>(a.coef + ((size_t)(a.S - 1) * a.C + c) * kRecStride + kBwdOff, tid, stg);
+        stage_store<REC>(cbuf, tid, stg);
+    }
     __syncthreads();
 
     for (int q = g; q < nchunk; q += a.G) {
@@ -565,22 +650,35 @@ __global__ __launch_bounds__(kThreads) void adi_bwd_kernel(SweepArgs a) {
         // with R_i the running sum of g.q and tau_{i+1} the time of the next processed sweep of
         // the same axis (0 after the very last one).  So Ax/Ay double as R and are never reset.
         const bool more = q + a.G < nchunk;
-        auto sweep = [&](auto AXC, int s) {
+#ifdef PDE_STAMP
+        unsigned long long stamps[16];
+        for (int i = 0; i < 16; ++i) stamps[i] = 0;
+#endif
+        auto body = [&](auto AXC, int s, const float* rec) {
             constexpr int AX = decltype(AXC)::value;
-            const int snext = (s > 0) ? s - 1 : a.S - 1;
-            const bool pre = (s > 0) || more;
-            if (pre) stage_load<REC>(a.coef + ((size_t)snext * a.C + c) * kRecStride + kBwdOff, tid, stg);
-            const float* rec = cbuf + (n & 1) * REC;
             const int axs = (AX >= 0) ? AX : tab->axis[s];
+#ifdef PDE_STAMP
+            const bool stamp_on = (blockIdx.x == 5 && wave == 3 && q == g && s >= 12 && s <= 14);
+            const int sb = (14 - s) * 5;                     // s=14 (x): 0.., s=13 (y): 5.., s=12 (x): 10..
+            PDE_STAMP_AT(sb + 0);
+#endif
             float dts = tab->dts[s];
             if (more && s == tab->first_s[axs]) dts -= tab->t_last[axs];
             if (axs == PDE_AXIS_Y) {
 #pragma unroll
                 for (int j = 0; j < J; ++j) relayout<N>(r[j], T, l, hf);
+                PDE_STAMP_AT(sb + 1);
                 solve_adj<M, J>(r, rec, l, hf);
+                PDE_STAMP_AT(sb + 2);
 #pragma unroll
                 for (int j = 0; j < J; ++j) relayout<N>(r[j], T, l, hf);
+                PDE_STAMP_AT(sb + 3);
+#if !(defined(PDE_ABL) && PDE_ABL == 2)
                 state_y<N, J, MASKED>(r, x, Ay, rec, l, hf, a.smooth3);
+                PDE_STAMP_AT(sb + 4);
+#else
+                Ay[0] += r[0][0];
+#endif
                 if (dts != 0.f) {
 #pragma unroll
                     for (int k = 0; k < M; ++k) Ty[k] = fmaf(dts, Ay[k], Ty[k]);
@@ -589,8 +687,15 @@ __global__ __launch_bounds__(kThreads) void adi_bwd_kernel(SweepArgs a) {
                 float xin[J];                             // partner half's innermost state: issue the
 #pragma unroll
                 for (int j = 0; j < J; ++j) xin[j] = xchg_half(x[j][M - 1]);   // exchange now, use it after the solve
+                PDE_STAMP_AT(sb + 1);
                 solve_adj<M, J>(r, rec, l, hf);
+                PDE_STAMP_AT(sb + 2);
+#if !(defined(PDE_ABL) && PDE_ABL == 2)
                 state_x<M, J, MASKED>(r, x, Ax, xin, rec, l, hf, a.smooth3);
+                PDE_STAMP_AT(sb + 3);
+#else
+                Ax[0] += xin[0] + r[0][0];
+#endif
                 if (dts != 0.f) {
 #pragma unroll
                     for (int k = 0; k < M; ++k) Tx[k] = fmaf(dts, Ax[k], Tx[k]);
@@ -607,23 +712,44 @@ __global__ __launch_bounds__(kThreads) void adi_bwd_kernel(SweepArgs a) {
                     for (int k = 0; k < M; ++k) x[j][k] *= sc;
                 }
             }
-            if (pre) stage_store<REC>(cbuf + ((n + 1) & 1) * REC, tid, stg);
-            __syncthreads();
-            ++n;
         };
-        if constexpr (SPLIT == kSplitStrang) {
-            for (int s = a.S - 1; s >= 0; s -= 3) {
-                sweep(std::integral_constant<int, PDE_AXIS_X>{}, s);
-                sweep(std::integral_constant<int, PDE_AXIS_Y>{}, s - 1);
-                sweep(std::integral_constant<int, PDE_AXIS_X>{}, s - 2);
-            }
-        } else if constexpr (SPLIT == kSplitLie) {
-            for (int s = a.S - 1; s >= 0; s -= 2) {
-                sweep(std::integral_constant<int, PDE_AXIS_Y>{}, s);
-                sweep(std::integral_constant<int, PDE_AXIS_X>{}, s - 1);
+        if constexpr (ST::kStep) {
+            for (int s = a.S - 1; s >= 0; s -= SPS) {
+                const int nxt = (s - SPS >= 0) ? s - SPS : (more ? a.S - 1 : -1);
+                if (nxt >= 0) dma_step((n + 1) & 1, nxt);     // lands during this step, read in the next
+                const float* base = cbuf + (size_t)(n & 1) * SPS * RECP;
+                if constexpr (SPLIT == kSplitStrang) {
+                    body(std::integral_constant<int, PDE_AXIS_X>{}, s, base);
+                    body(std::integral_constant<int, PDE_AXIS_Y>{}, s - 1, base + RECP);
+                    body(std::integral_constant<int, PDE_AXIS_X>{}, s - 2, base + 2 * RECP);
+                } else {
+                    body(std::integral_constant<int, PDE_AXIS_Y>{}, s, base);
+                    body(std::integral_constant<int, PDE_AXIS_X>{}, s - 1, base + RECP);
+                }
+#ifdef PDE_STAMP
+                if (blockIdx.x == 5 && wave == 3 && q == g && s == 14) stamps[15] = stamp();
+#endif
+                dma_wait_all();                           // my DMA pieces (issued a whole step ago) have landed
+                __syncthreads();                          // ... everyone's have, and everyone is done reading
+#ifdef PDE_STAMP
+                if (blockIdx.x == 5 && wave == 3 && q == g && s == 14 && lane == 0) {
+                    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.dbg);
+                    for (int i = 0; i < 16; ++i) dbg[i] = stamps[i];
+                    dbg[16] = stamp();
+                }
+#endif
+                ++n;
             }
         } else {
-            for (int s = a.S - 1; s >= 0; --s) sweep(std::integral_constant<int, -1>{}, s);
+            for (int s = a.S - 1; s >= 0; --s) {
+                const int snext = (s > 0) ? s - 1 : a.S - 1;
+                const bool pre = (s > 0) || more;
+                if (pre) stage_load<REC>(a.coef + ((size_t)snext * a.C + c) * kRecStride + kBwdOff, tid, stg);
+                body(std::integral_constant<int, -1>{}, s, cbuf + (n & 1) * RECP);
+                if (pre) stage_store<REC>(cbuf + ((n + 1) & 1) * RECP, tid, stg);
+                __syncthreads();
+                ++n;
+            }
         }
 #pragma unroll
         for (int j = 0; j < J; ++j) {

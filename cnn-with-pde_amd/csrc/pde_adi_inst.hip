@@ -41,14 +41,17 @@ int fwd_io(int split, const SweepArgs& sa, int grid, size_t lds, hipStream_t st)
     }
 }
 
+template <bool MASKED, int SPLIT>
+constexpr size_t bwd_lds() { return (size_t)(BwdStage<MASKED, SPLIT>::kFloats + kWaves * kImage) * sizeof(float); }
+
 template <typename IO>
-int bwd_io(int split, int masked, const SweepArgs& sa, int grid, size_t lds, hipStream_t st) {
+int bwd_io(int split, int masked, const SweepArgs& sa, int grid, size_t /*lds*/, hipStream_t st) {
     constexpr int N = PDE_INST_N;
-    if (masked) return launch(adi_bwd_kernel<N, 1, IO, true, kSplitAny>, sa, grid, lds, st);   // rare path
+    if (masked) return launch(adi_bwd_kernel<N, 1, IO, true, kSplitAny>, sa, grid, bwd_lds<true, kSplitAny>(), st);   // rare path
     switch (split) {
-        case kSplitStrang: return launch(adi_bwd_kernel<N, kJBwd, IO, false, kSplitStrang>, sa, grid, lds, st);
-        case kSplitLie: return launch(adi_bwd_kernel<N, kJBwd, IO, false, kSplitLie>, sa, grid, lds, st);
-        default: return launch(adi_bwd_kernel<N, 1, IO, false, kSplitAny>, sa, grid, lds, st);
+        case kSplitStrang: return launch(adi_bwd_kernel<N, kJBwd, IO, false, kSplitStrang>, sa, grid, bwd_lds<false, kSplitStrang>(), st);
+        case kSplitLie: return launch(adi_bwd_kernel<N, kJBwd, IO, false, kSplitLie>, sa, grid, bwd_lds<false, kSplitLie>(), st);
+        default: return launch(adi_bwd_kernel<N, 1, IO, false, kSplitAny>, sa, grid, bwd_lds<false, kSplitAny>(), st);
     }
 }
 

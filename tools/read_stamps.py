@@ -1,0 +1,30 @@
+"""Run one backward of the bench workload with the stamped library and print phase durations."""
+import contextlib, io, os, sys, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import cnn_with_pde_amd as P
+from cnn_with_pde_amd import functional as F_
+orig = F_._workspace
+keep = {}
+def ws_hook(n, dev):
+    t = orig(n, dev); keep["ws"] = t; return t
+F_._workspace = ws_hook
+with contextlib.redirect_stdout(io.StringIO()):
+    layer = P.EnhancedDiffusionLayer(32, 64, num_steps=10, channel_mixing_enabled=False).cuda()
+u = torch.randn(512, 64, 32, 32, device="cuda", requires_grad=True)
+gy = torch.randn_like(u)
+for it in range(3):
+    y = layer(u); y.backward(gy)
+torch.cuda.synchronize()
+ws = keep["ws"]     # last workspace allocated = the backward's
+from cnn_with_pde_amd import _lib as L
+lib = L.load()
+# offset of the partials inside the backward workspace: coef + tab + flags
+d = F_._make_desc(512, 64, 32, 0, [s for st in P.adi_schedule(0.001, 1, 1, 10) for s in st], False, 10.0, 1e-6)
+total = lib.pde_adi_backward_workspace_bytes(C.byref(d), 0)
+off = total - 512 - 0          # diagnostics scratch sits right before the (empty) checkpoint area
+st = ws[off:off + 17 * 8].cpu().view(torch.int64).tolist()
+names = {0: "x-sweep s=14", 5: "y-sweep s=13", 10: "x-sweep s=12"}
+for b in (0, 5, 10):
+    print(names[b], [st[b + i + 1] - st[b + i] for i in range(4) if st[b + i + 1] and st[b + i]])
+print("step total", st[15] - st[0], "barrier wait", st[16] - st[15])
