@@ -364,9 +364,9 @@ size_t tab_bytes() { return align_up(sizeof(SweepTab), 256); }
 size_t flag_bytes(const PdeAdiDesc* d) { return align_up((size_t)d->C * sizeof(int), 256); }
 
 
-// Workgroups per channel.  With C a multiple of 8 the XCD-ordered map is used and a channel gets one
-// XCD's worth of workgroups (32 CUs x wg_per_cu) when the batch has that many chunks; otherwise
-// just enough groups to fill the chip once.
+// Workgroups per channel: just enough groups to fill the chip once (measured: more groups per channel
+// cost more in per-workgroup prologue/epilogue and partial sums than they gain in L2 locality).
+// With C a multiple of 8 the XCD-ordered block map keeps a channel's groups on one XCD.
 int env_int(const char* name, int dflt) {           // developer tuning knobs (tools/, never needed in production)
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
@@ -374,7 +374,7 @@ int env_int(const char* name, int dflt) {           // developer tuning knobs (t
 bool use_xcd_map(const PdeAdiDesc* d) { return (d->C % 8) == 0 && env_int("PDE_XCD", 1) != 0; }
 int groups_per_channel(const PdeAdiDesc* d, int planes_per_iter, int wg_per_cu) {
     const int nchunk = (d->B + planes_per_iter - 1) / planes_per_iter;
-    int G = use_xcd_map(d) ? 32 * wg_per_cu : (256 * wg_per_cu + d->C - 1) / d->C;
+    int G = (256 * wg_per_cu + d->C - 1) / d->C;
     G = env_int(wg_per_cu == 8 / kWaves ? "PDE_G_BWD" : "PDE_G_FWD", G);
     if (G < 1) G = 1;
     if (G > nchunk) G = nchunk;

@@ -300,6 +300,14 @@ __device__ __forceinline__ void relayout(float (&v)[Geo<N>::M], float* T, int l,
     __builtin_amdgcn_wave_barrier();
 }
 
+// (A two-planes-at-once variant with ds_write_b64 was measured and dropped: 3-6 % slower in both
+// kernels; the LDS store path gains nothing from 8-byte stores in this scatter.)
+template <int N, int J>
+__device__ __forceinline__ void relayout_all(float (&v)[J][Geo<N>::M], float* T, int l, int hf) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) relayout<N>(v[j], T, l, hf);
+}
+
 template <int M>
 __device__ __forceinline__ void load_half(const float* src, float (&dst)[M]) {
 #pragma unroll
@@ -418,15 +426,9 @@ __global__ __launch_bounds__(kThreads) void adi_fwd_kernel(SweepArgs a) {
 #endif
             const float* rec = cbuf + (n & 1) * kRecFwd;
             const int axs = (AX >= 0) ? AX : tab->axis[s];
-            if (axs == PDE_AXIS_Y) {
-#pragma unroll
-                for (int j = 0; j < J; ++j) relayout<N>(v[j], T, l, hf);
-            }
+            if (axs == PDE_AXIS_Y) relayout_all<N, J>(v, T, l, hf);
             solve_fwd<M, J>(v, rec, l, hf);
-            if (axs == PDE_AXIS_Y) {
-#pragma unroll
-                for (int j = 0; j < J; ++j) relayout<N>(v[j], T, l, hf);
-            }
+            if (axs == PDE_AXIS_Y) relayout_all<N, J>(v, T, l, hf);
             if (a.ckpt != nullptr && ck_bit(a.ck, s)) {   // backward pre-pass: park this state (fp32)
                 float* slot = a.ckpt + (size_t)ck_slot(a.ck, s) * a.B * a.C * plane;
                 store_planes<N, J, float>(slot, q, wave, lane, l, hf, a.B, a.C, c, T, v);
@@ -617,6 +619,9 @@ __global__ __launch_bounds__(kThreads) void adi_bwd_kernel(SweepArgs a) {
     for (int k = 0; k < M; ++k) Ax[k] = Tx[k] = Ay[k] = Ty[k] = 0.f;
 
     for (int e = tid; e < kWaves * kImage; e += kThreads) tbuf[e] = 0.f;
+    // per-axis table entries: scalar loads once, not a dependent chain of them in every sweep
+    const int first_x = tab->first_s[0], first_y = tab->first_s[1];
+    const float tlast_x = tab->t_last[0], tlast_y = tab->t_last[1];
 
     // records of the step whose newest sweep is s_hi -> step buffer `buf` (slot r holds sweep s_hi - r)
     auto dma_step = [&](int buf, int s_hi) {
@@ -654,7 +659,7 @@ __global__ __launch_bounds__(kThreads) void adi_bwd_kernel(SweepArgs a) {
         unsigned long long stamps[16];
         for (int i = 0; i < 16; ++i) stamps[i] = 0;
 #endif
-        auto body = [&](auto AXC, int s, const float* rec) {
+        auto body = [&](auto AXC, int s, const float* rec, float dts) {
             constexpr int AX = decltype(AXC)::value;
             const int axs = (AX >= 0) ? AX : tab->axis[s];
 #ifdef PDE_STAMP
@@ -662,16 +667,13 @@ __global__ __launch_bounds__(kThreads) void adi_bwd_kernel(SweepArgs a) {
             const int sb = (14 - s) * 5;                     // s=14 (x): 0.., s=13 (y): 5.., s=12 (x): 10..
             PDE_STAMP_AT(sb + 0);
 #endif
-            float dts = tab->dts[s];
-            if (more && s == tab->first_s[axs]) dts -= tab->t_last[axs];
+            if (more && s == (axs == PDE_AXIS_Y ? first_y : first_x)) dts -= (axs == PDE_AXIS_Y ? tlast_y : tlast_x);
             if (axs == PDE_AXIS_Y) {
-#pragma unroll
-                for (int j = 0; j < J; ++j) relayout<N>(r[j], T, l, hf);
+                relayout_all<N, J>(r, T, l, hf);
                 PDE_STAMP_AT(sb + 1);
                 solve_adj<M, J>(r, rec, l, hf);
                 PDE_STAMP_AT(sb + 2);
-#pragma unroll
-                for (int j = 0; j < J; ++j) relayout<N>(r[j], T, l, hf);
+                relayout_all<N, J>(r, T, l, hf);
                 PDE_STAMP_AT(sb + 3);
 #if !(defined(PDE_ABL) && PDE_ABL == 2)
                 state_y<N, J, MASKED>(r, x, Ay, rec, l, hf, a.smooth3);
@@ -718,13 +720,15 @@ __global__ __launch_bounds__(kThreads) void adi_bwd_kernel(SweepArgs a) {
                 const int nxt = (s - SPS >= 0) ? s - SPS : (more ? a.S - 1 : -1);
                 if (nxt >= 0) dma_step((n + 1) & 1, nxt);     // lands during this step, read in the next
                 const float* base = cbuf + (size_t)(n & 1) * SPS * RECP;
+                const float d0 = tab->dts[s], d1 = tab->dts[s - 1];          // issued together, up front
                 if constexpr (SPLIT == kSplitStrang) {
-                    body(std::integral_constant<int, PDE_AXIS_X>{}, s, base);
-                    body(std::integral_constant<int, PDE_AXIS_Y>{}, s - 1, base + RECP);
-                    body(std::integral_constant<int, PDE_AXIS_X>{}, s - 2, base + 2 * RECP);
+                    const float d2 = tab->dts[s - 2];
+                    body(std::integral_constant<int, PDE_AXIS_X>{}, s, base, d0);
+                    body(std::integral_constant<int, PDE_AXIS_Y>{}, s - 1, base + RECP, d1);
+                    body(std::integral_constant<int, PDE_AXIS_X>{}, s - 2, base + 2 * RECP, d2);
                 } else {
-                    body(std::integral_constant<int, PDE_AXIS_Y>{}, s, base);
-                    body(std::integral_constant<int, PDE_AXIS_X>{}, s - 1, base + RECP);
+                    body(std::integral_constant<int, PDE_AXIS_Y>{}, s, base, d0);
+                    body(std::integral_constant<int, PDE_AXIS_X>{}, s - 1, base + RECP, d1);
                 }
 #ifdef PDE_STAMP
                 if (blockIdx.x == 5 && wave == 3 && q == g && s == 14) stamps[15] = stamp();
@@ -745,7 +749,7 @@ __global__ __launch_bounds__(kThreads) void adi_bwd_kernel(SweepArgs a) {
                 const int snext = (s > 0) ? s - 1 : a.S - 1;
                 const bool pre = (s > 0) || more;
                 if (pre) stage_load<REC>(a.coef + ((size_t)snext * a.C + c) * kRecStride + kBwdOff, tid, stg);
-                body(std::integral_constant<int, -1>{}, s, cbuf + (n & 1) * RECP);
+                body(std::integral_constant<int, -1>{}, s, cbuf + (n & 1) * RECP, tab->dts[s]);
                 if (pre) stage_store<REC>(cbuf + ((n + 1) & 1) * RECP, tid, stg);
                 __syncthreads();
                 ++n;
