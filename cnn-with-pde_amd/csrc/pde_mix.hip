@@ -111,6 +111,171 @@ __global__ void mix_gm_reduce_kernel(const float* __restrict__ part, float* __re
     gM[e] = s;
 }
 
+// ---- fp32 MFMA path (C a multiple of 32) -------------------------------------------------
+// out = W u per pixel is a (C x C) x (C x pixels) product: v_mfma_f32_32x32x2_f32 runs it at the
+// fp32 vector rate with exact fp32 FMA chains and leaves the VALU free, so the kernel is bound by
+// streaming u in and out once (8 B/element).  Operand maps (cdna_hip_programming.md §3):
+//   A: lane l holds A[i = l&31][k = l>>5]      B: lane l holds B[k = l>>5][j = l&31]
+//   D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5)
+// Each wave takes 128 consecutive pixels of one sample: lane (j, kh) loads 4 consecutive pixels
+// (one 16-byte load) of channel 2*ks+kh — component q is the B operand of sub-strip q — so the four
+// D values of a lane are 4 consecutive pixels again and go out as one 16-byte store.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <typename IO> struct Io4;
+template <> struct Io4<float> {
+    __device__ static __forceinline__ float4 ld(const float* p) { return *reinterpret_cast<const float4*>(p); }
+    __device__ static __forceinline__ void st(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+};
+template <> struct Io4<bf16s> {
+    __device__ static __forceinline__ float4 ld(const bf16s* p) {
+        const ushort4 q = *reinterpret_cast<const ushort4*>(p);
+        return make_float4(__uint_as_float((unsigned)q.x << 16), __uint_as_float((unsigned)q.y << 16),
+                           __uint_as_float((unsigned)q.z << 16), __uint_as_float((unsigned)q.w << 16));
+    }
+    __device__ static __forceinline__ void st(bf16s* p, float4 v) {
+        bf16s t[4];
+        Io<bf16s>::st(&t[0], v.x); Io<bf16s>::st(&t[1], v.y); Io<bf16s>::st(&t[2], v.z); Io<bf16s>::st(&t[3], v.w);
+        *reinterpret_cast<ushort4*>(p) = make_ushort4(t[0].v, t[1].v, t[2].v, t[3].v);
+    }
+};
+
+constexpr int kMixTG = 2;      // output-channel tiles (of 32) accumulated per pass over the input
+
+template <typename IO>
+__global__ __launch_bounds__(256) void mix_apply_mfma_kernel(const IO* __restrict__ u, const float* __restrict__ M,
+                                                             IO* __restrict__ out, int B, int C, int HW, int trans) {
+    extern __shared__ float wfrag[];                    // [C/32 tiles][C/2 k-steps][64 lanes]: A fragments of W
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int T = C / 32, KS = C / 2;
+    for (int e = tid; e < C * C; e += 256) {
+        const int ln = e & 63, ks = (e >> 6) % KS, it = (e >> 6) / KS;
+        const int i = 32 * it + (ln & 31), k = 2 * ks + (ln >> 5);
+        wfrag[e] = trans ? M[k * C + i] : M[i * C + k];
+    }
+    __syncthreads();
+    const int per_sample = (HW + 127) / 128;
+    const long nblk = (long)B * per_sample;
+    const int kh = lane >> 5, jj = lane & 31;
+    for (long blk = (long)blockIdx.x * 4 + wave; blk < nblk; blk += (long)gridDim.x * 4) {
+        const int b = (int)(blk / per_sample);
+        const int px = (int)(blk % per_sample) * 128 + 4 * jj;
+        const bool pv = px < HW;                        // HW is a multiple of 4: all four pixels or none
+        const IO* ub = u + (size_t)b * C * HW + px;
+        IO* ob = out + (size_t)b * C * HW + px;
+        for (int t0 = 0; t0 < T; t0 += kMixTG) {
+            f32x16 acc[kMixTG][4];
+#pragma unroll
+            for (int t = 0; t < kMixTG; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][q][r] = 0.f;
+#pragma unroll 4
+            for (int ks = 0; ks < KS; ++ks) {
+                const float4 x = pv ? Io4<IO>::ld(ub + (size_t)(2 * ks + kh) * HW) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int t = 0; t < kMixTG; ++t) {
+                    if (t0 + t < T) {
+                        const float av = wfrag[((t0 + t) * KS + ks) * 64 + lane];
+                        acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, x.x, acc[t][0], 0, 0, 0);
+                        acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, x.y, acc[t][1], 0, 0, 0);
+                        acc[t][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, x.z, acc[t][2], 0, 0, 0);
+                        acc[t][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, x.w, acc[t][3], 0, 0, 0);
+                    }
+                }
+            }
+            if (pv) {
+#pragma unroll
+                for (int t = 0; t < kMixTG; ++t) {
+                    if (t0 + t < T) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int ch = 32 * (t0 + t) + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                            Io4<IO>::st(ob + (size_t)ch * HW, make_float4(acc[t][0][r], acc[t][1][r], acc[t][2][r], acc[t][3][r]));
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// gM = G U^T with the pixel index as the contraction: A[i][k] = g[channel i][pixel k],
+// B[k][j] = u[channel j][pixel k].  Both operands have the CHANNEL on the lane, so tiles
+// [C channels][32 pixels] are staged through LDS (coalesced 16-byte loads, stride-33 rows for
+// conflict-free fragment reads).  Wave w owns output tiles w, w+4, ... of the (C/32)^2 grid; the
+// pixel range is split over workgroups and the partial matrices are added in a fixed order.
+constexpr int kGmKP = 32;
+template <typename IO>
+__global__ __launch_bounds__(256) void mix_gm_mfma_kernel(const IO* __restrict__ u, const IO* __restrict__ g,
+                                                          float* __restrict__ part, int B, int C, int HW, int nsplit) {
+    extern __shared__ float sm[];                      // [2][C][33]
+    float* sg = sm;
+    float* su = sm + C * (kGmKP + 1);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int T = C / 32, ntile = T * T;
+    const int kh = lane >> 5, jj = lane & 31;
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int per_sample = (HW + kGmKP - 1) / kGmKP;
+    const long total = (long)B * per_sample;
+    for (long ch = blockIdx.x; ch < total; ch += nsplit) {
+        const int b = (int)(ch / per_sample);
+        const int p0 = (int)(ch % per_sample) * kGmKP;
+        __syncthreads();                               // previous chunk fully consumed
+        for (int e = tid; e < C * (kGmKP / 4); e += 256) {
+            const int c = e / (kGmKP / 4), c4 = e % (kGmKP / 4);
+            const int p = p0 + 4 * c4;
+            const bool pv = p < HW;
+            const size_t off = ((size_t)b * C + c) * HW + p;
+            const float4 gv = pv ? Io4<IO>::ld(g + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 uv = pv ? Io4<IO>::ld(u + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float* dg = sg + c * (kGmKP + 1) + 4 * c4;
+            float* du = su + c * (kGmKP + 1) + 4 * c4;
+            dg[0] = gv.x; dg[1] = gv.y; dg[2] = gv.z; dg[3] = gv.w;
+            du[0] = uv.x; du[1] = uv.y; du[2] = uv.z; du[3] = uv.w;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int ks = 0; ks < kGmKP / 2; ++ks) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int tile = wave + 4 * t;
+                if (tile < ntile) {
+                    const int it = tile / T, jt = tile % T;
+                    const float av = sg[(32 * it + jj) * (kGmKP + 1) + 2 * ks + kh];
+                    const float bv = su[(32 * jt + jj) * (kGmKP + 1) + 2 * ks + kh];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    float* dst = part + (size_t)blockIdx.x * C * C;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int tile = wave + 4 * t;
+        if (tile < ntile) {
+            const int it = tile / T, jt = tile % T;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = 32 * it + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                dst[i * C + 32 * jt + jj] = acc[t][r];
+            }
+        }
+    }
+}
+
+bool mfma_apply_ok(int C, int HW) { return (C % 32) == 0 && C <= 128 && (HW % 4) == 0; }   // W fragments: C*C*4 B of LDS
+bool mfma_gm_ok(int C, int HW) { return (C == 64 || C == 128) && (HW % 4) == 0; }
+int gm_mfma_splits(int B, int HW) {
+    const long chunks = (long)B * ((HW + kGmKP - 1) / kGmKP);
+    return (int)(chunks < 512 ? chunks : 512);
+}
+
 int gm_splits(int B, int C, int HW) {
     const int tiles = (C + kT - 1) / kT;
     const long chunks = (long)B * ((HW + kK - 1) / kK);
@@ -118,6 +283,24 @@ int gm_splits(int B, int C, int HW) {
     if (n < 1) n = 1;
     if (n > chunks) n = chunks;
     return (int)n;
+}
+
+int launch_apply_mfma(int B, int C, int HW, int io, const void* u, const float* M, void* out, int trans,
+                      hipStream_t st) {
+    const size_t lds = (size_t)C * C * sizeof(float);
+    const long nblk = (long)B * ((HW + 127) / 128);
+    long grid = (nblk + 3) / 4;
+    if (grid > 1024) grid = 1024;
+    if (io == PDE_IO_F32) {
+        static bool cfg = false;
+        if (!cfg) { (void)hipFuncSetAttribute((const void*)mix_apply_mfma_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); cfg = true; }
+        hipLaunchKernelGGL((mix_apply_mfma_kernel<float>), dim3((unsigned)grid), dim3(256), lds, st, (const float*)u, M, (float*)out, B, C, HW, trans);
+    } else {
+        static bool cfg = false;
+        if (!cfg) { (void)hipFuncSetAttribute((const void*)mix_apply_mfma_kernel<bf16s>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); cfg = true; }
+        hipLaunchKernelGGL((mix_apply_mfma_kernel<bf16s>), dim3((unsigned)grid), dim3(256), lds, st, (const bf16s*)u, M, (bf16s*)out, B, C, HW, trans);
+    }
+    return check_launch();
 }
 
 }  // namespace
@@ -131,19 +314,20 @@ int pde_channel_mix_forward(int32_t B, int32_t C, int32_t HW, int32_t io_dtype, 
                             void* out, void* stream) {
     if (B <= 0 || C <= 0 || HW <= 0 || !u || !M || !out) return PDE_E_BADARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (io_dtype != PDE_IO_F32 && io_dtype != PDE_IO_BF16) return PDE_E_BADARG;
+    if (mfma_apply_ok(C, HW)) return launch_apply_mfma(B, C, HW, io_dtype, u, M, out, 0, st);
     dim3 grid((HW + 255) / 256, B);
     if (io_dtype == PDE_IO_F32)
         hipLaunchKernelGGL((mix_apply_kernel<float, false>), grid, dim3(256), 0, st, (const float*)u, M, (float*)out, C, HW);
-    else if (io_dtype == PDE_IO_BF16)
-        hipLaunchKernelGGL((mix_apply_kernel<bf16s, false>), grid, dim3(256), 0, st, (const bf16s*)u, M, (bf16s*)out, C, HW);
     else
-        return PDE_E_BADARG;
+        hipLaunchKernelGGL((mix_apply_kernel<bf16s, false>), grid, dim3(256), 0, st, (const bf16s*)u, M, (bf16s*)out, C, HW);
     return check_launch();
 }
 
 size_t pde_channel_mix_backward_workspace_bytes(int32_t B, int32_t C, int32_t HW) {
     if (B <= 0 || C <= 0 || HW <= 0) return 0;
-    return (size_t)gm_splits(B, C, HW) * C * C * sizeof(float);
+    const int n = mfma_gm_ok(C, HW) ? gm_mfma_splits(B, HW) : gm_splits(B, C, HW);
+    return (size_t)n * C * C * sizeof(float);
 }
 
 int pde_channel_mix_backward(int32_t B, int32_t C, int32_t HW, int32_t io_dtype, const void* u, const void* gout,
@@ -152,20 +336,41 @@ int pde_channel_mix_backward(int32_t B, int32_t C, int32_t HW, int32_t io_dtype,
     if (B <= 0 || C <= 0 || HW <= 0 || !u || !gout || !M || !gu || !gM || !workspace) return PDE_E_BADARG;
     if (workspace_bytes < pde_channel_mix_backward_workspace_bytes(B, C, HW)) return PDE_E_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (io_dtype != PDE_IO_F32 && io_dtype != PDE_IO_BF16) return PDE_E_BADARG;
     dim3 grid((HW + 255) / 256, B);
     const int tiles = (C + kT - 1) / kT;
-    const int nsplit = gm_splits(B, C, HW);
     float* part = static_cast<float*>(workspace);
-    if (io_dtype == PDE_IO_F32) {
+    // gu = M^T gout
+    if (mfma_apply_ok(C, HW)) {
+        const int rc = launch_apply_mfma(B, C, HW, io_dtype, gout, M, gu, 1, st);
+        if (rc != PDE_OK) return rc;
+    } else if (io_dtype == PDE_IO_F32) {
         hipLaunchKernelGGL((mix_apply_kernel<float, true>), grid, dim3(256), 0, st, (const float*)gout, M, (float*)gu, C, HW);
-        hipLaunchKernelGGL((mix_gm_kernel<float>), dim3(tiles * tiles, nsplit), dim3(256), 0, st, (const float*)u,
-                           (const float*)gout, part, B, C, HW, nsplit);
-    } else if (io_dtype == PDE_IO_BF16) {
-        hipLaunchKernelGGL((mix_apply_kernel<bf16s, true>), grid, dim3(256), 0, st, (const bf16s*)gout, M, (bf16s*)gu, C, HW);
-        hipLaunchKernelGGL((mix_gm_kernel<bf16s>), dim3(tiles * tiles, nsplit), dim3(256), 0, st, (const bf16s*)u,
-                           (const bf16s*)gout, part, B, C, HW, nsplit);
     } else {
-        return PDE_E_BADARG;
+        hipLaunchKernelGGL((mix_apply_kernel<bf16s, true>), grid, dim3(256), 0, st, (const bf16s*)gout, M, (bf16s*)gu, C, HW);
+    }
+    // gM = G U^T
+    int nsplit;
+    if (mfma_gm_ok(C, HW)) {
+        nsplit = gm_mfma_splits(B, HW);
+        const size_t lds = (size_t)2 * C * (kGmKP + 1) * sizeof(float);
+        if (io_dtype == PDE_IO_F32) {
+            static bool cfg = false;
+            if (!cfg) { (void)hipFuncSetAttribute((const void*)mix_gm_mfma_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024); cfg = true; }
+            hipLaunchKernelGGL((mix_gm_mfma_kernel<float>), dim3(nsplit), dim3(256), lds, st, (const float*)u, (const float*)gout, part, B, C, HW, nsplit);
+        } else {
+            static bool cfg = false;
+            if (!cfg) { (void)hipFuncSetAttribute((const void*)mix_gm_mfma_kernel<bf16s>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024); cfg = true; }
+            hipLaunchKernelGGL((mix_gm_mfma_kernel<bf16s>), dim3(nsplit), dim3(256), lds, st, (const bf16s*)u, (const bf16s*)gout, part, B, C, HW, nsplit);
+        }
+    } else {
+        nsplit = gm_splits(B, C, HW);
+        if (io_dtype == PDE_IO_F32)
+            hipLaunchKernelGGL((mix_gm_kernel<float>), dim3(tiles * tiles, nsplit), dim3(256), 0, st, (const float*)u,
+                               (const float*)gout, part, B, C, HW, nsplit);
+        else
+            hipLaunchKernelGGL((mix_gm_kernel<bf16s>), dim3(tiles * tiles, nsplit), dim3(256), 0, st, (const bf16s*)u,
+                               (const bf16s*)gout, part, B, C, HW, nsplit);
     }
     hipLaunchKernelGGL(mix_gm_reduce_kernel, dim3((C * C + 255) / 256), dim3(256), 0, st, part, gM, C * C, nsplit);
     return check_launch();

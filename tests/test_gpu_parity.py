@@ -173,7 +173,7 @@ def test_generic_schedule_equals_composition():
         assert G.rel_err(q1.grad.cpu(), q2.grad.cpu()) <= TOL
 
 
-@pytest.mark.parametrize("C,HW", [(3, 1024), (64, 1024), (7, 49)])
+@pytest.mark.parametrize("C,HW", [(3, 1024), (64, 1024), (7, 49), (32, 784), (128, 256), (96, 64)])
 def test_channel_mix_vs_fp64(C, HW):
     import cnn_with_pde_amd as P
     g = torch.Generator().manual_seed(C)
