@@ -103,12 +103,18 @@ __global__ __launch_bounds__(256) void mix_gm_kernel(const IO* __restrict__ u, c
     if (i + 1 < C && j + 1 < C) dst[(i + 1) * C + j + 1] = a11;
 }
 
-__global__ void mix_gm_reduce_kernel(const float* __restrict__ part, float* __restrict__ gM, int CC, int nsplit) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= CC) return;
+__global__ __launch_bounds__(256) void mix_gm_reduce_kernel(const float* __restrict__ part, float* __restrict__ gM,
+                                                            int CC, int nsplit) {
+    // 64 outputs per workgroup; thread (q, e) adds splits q, q+4, ... of output e, the four partial
+    // sums are combined in a fixed order (bitwise reproducible)
+    __shared__ float sh[4][64];
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
     float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * CC + e];
-    gM[e] = s;
+    if (e < CC)
+        for (int k = q; k < nsplit; k += 4) s += part[(size_t)k * CC + e];
+    sh[q][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (q == 0 && e < CC) gM[e] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
 }
 
 // ---- fp32 MFMA path (C a multiple of 32) -------------------------------------------------
@@ -171,19 +177,35 @@ __global__ __launch_bounds__(256) void mix_apply_mfma_kernel(const IO* __restric
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[t][q][r] = 0.f;
-#pragma unroll 4
-            for (int ks = 0; ks < KS; ++ks) {
-                const float4 x = pv ? Io4<IO>::ld(ub + (size_t)(2 * ks + kh) * HW) : make_float4(0.f, 0.f, 0.f, 0.f);
+            // input loads run one batch of 4 k-steps ahead of the MFMAs (two register sets)
+            auto fetch = [&](float4 (&x)[4], int ks0) {
 #pragma unroll
-                for (int t = 0; t < kMixTG; ++t) {
-                    if (t0 + t < T) {
-                        const float av = wfrag[((t0 + t) * KS + ks) * 64 + lane];
-                        acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, x.x, acc[t][0], 0, 0, 0);
-                        acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, x.y, acc[t][1], 0, 0, 0);
-                        acc[t][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, x.z, acc[t][2], 0, 0, 0);
-                        acc[t][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, x.w, acc[t][3], 0, 0, 0);
+                for (int i = 0; i < 4; ++i)
+                    x[i] = (pv && ks0 + i < KS) ? Io4<IO>::ld(ub + (size_t)(2 * (ks0 + i) + kh) * HW)
+                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+            };
+            auto consume = [&](const float4 (&x)[4], int ks0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int t = 0; t < kMixTG; ++t) {
+                        if (t0 + t < T) {
+                            const float av = wfrag[((t0 + t) * KS + ks0 + i) * 64 + lane];
+                            acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, x[i].x, acc[t][0], 0, 0, 0);
+                            acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, x[i].y, acc[t][1], 0, 0, 0);
+                            acc[t][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, x[i].z, acc[t][2], 0, 0, 0);
+                            acc[t][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, x[i].w, acc[t][3], 0, 0, 0);
+                        }
                     }
                 }
+            };
+            float4 xa[4], xb[4];
+            fetch(xa, 0);
+            for (int ks0 = 0; ks0 < KS; ks0 += 8) {          // KS = C/2 is a multiple of 16
+                fetch(xb, ks0 + 4);
+                consume(xa, ks0);
+                fetch(xa, ks0 + 8);
+                consume(xb, ks0 + 4);
             }
             if (pv) {
 #pragma unroll
@@ -206,13 +228,14 @@ __global__ __launch_bounds__(256) void mix_apply_mfma_kernel(const IO* __restric
 // [C channels][32 pixels] are staged through LDS (coalesced 16-byte loads, stride-33 rows for
 // conflict-free fragment reads).  Wave w owns output tiles w, w+4, ... of the (C/32)^2 grid; the
 // pixel range is split over workgroups and the partial matrices are added in a fixed order.
-constexpr int kGmKP = 32;
+constexpr int kGmKP = 64;      // pixels per staged chunk
+constexpr int kGmLd = kGmKP + 2; // row stride (floats): even for 8-byte stores, 2*ch+p banks stay distinct
 template <typename IO>
 __global__ __launch_bounds__(256) void mix_gm_mfma_kernel(const IO* __restrict__ u, const IO* __restrict__ g,
                                                           float* __restrict__ part, int B, int C, int HW, int nsplit) {
-    extern __shared__ float sm[];                      // [2][C][33]
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [2][C][kGmLd]
     float* sg = sm;
-    float* su = sm + C * (kGmKP + 1);
+    float* su = sm + C * kGmLd;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int T = C / 32, ntile = T * T;
     const int kh = lane >> 5, jj = lane & 31;
@@ -234,10 +257,10 @@ __global__ __launch_bounds__(256) void mix_gm_mfma_kernel(const IO* __restrict__
             const size_t off = ((size_t)b * C + c) * HW + p;
             const float4 gv = pv ? Io4<IO>::ld(g + off) : make_float4(0.f, 0.f, 0.f, 0.f);
             const float4 uv = pv ? Io4<IO>::ld(u + off) : make_float4(0.f, 0.f, 0.f, 0.f);
-            float* dg = sg + c * (kGmKP + 1) + 4 * c4;
-            float* du = su + c * (kGmKP + 1) + 4 * c4;
-            dg[0] = gv.x; dg[1] = gv.y; dg[2] = gv.z; dg[3] = gv.w;
-            du[0] = uv.x; du[1] = uv.y; du[2] = uv.z; du[3] = uv.w;
+            float* dg = sg + c * kGmLd + 4 * c4;
+            float* du = su + c * kGmLd + 4 * c4;
+            *reinterpret_cast<float2*>(dg) = make_float2(gv.x, gv.y); *reinterpret_cast<float2*>(dg + 2) = make_float2(gv.z, gv.w);
+            *reinterpret_cast<float2*>(du) = make_float2(uv.x, uv.y); *reinterpret_cast<float2*>(du + 2) = make_float2(uv.z, uv.w);
         }
         __syncthreads();
 #pragma unroll 4
@@ -247,8 +270,8 @@ __global__ __launch_bounds__(256) void mix_gm_mfma_kernel(const IO* __restrict__
                 const int tile = wave + 4 * t;
                 if (tile < ntile) {
                     const int it = tile / T, jt = tile % T;
-                    const float av = sg[(32 * it + jj) * (kGmKP + 1) + 2 * ks + kh];
-                    const float bv = su[(32 * jt + jj) * (kGmKP + 1) + 2 * ks + kh];
+                    const float av = sg[(32 * it + jj) * kGmLd + 2 * ks + kh];
+                    const float bv = su[(32 * jt + jj) * kGmLd + 2 * ks + kh];
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
                 }
             }
@@ -353,7 +376,7 @@ int pde_channel_mix_backward(int32_t B, int32_t C, int32_t HW, int32_t io_dtype,
     int nsplit;
     if (mfma_gm_ok(C, HW)) {
         nsplit = gm_mfma_splits(B, HW);
-        const size_t lds = (size_t)2 * C * (kGmKP + 1) * sizeof(float);
+        const size_t lds = (size_t)2 * C * kGmLd * sizeof(float);
         if (io_dtype == PDE_IO_F32) {
             static bool cfg = false;
             if (!cfg) { (void)hipFuncSetAttribute((const void*)mix_gm_mfma_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024); cfg = true; }
@@ -372,7 +395,7 @@ int pde_channel_mix_backward(int32_t B, int32_t C, int32_t HW, int32_t io_dtype,
             hipLaunchKernelGGL((mix_gm_kernel<bf16s>), dim3(tiles * tiles, nsplit), dim3(256), 0, st, (const bf16s*)u,
                                (const bf16s*)gout, part, B, C, HW, nsplit);
     }
-    hipLaunchKernelGGL(mix_gm_reduce_kernel, dim3((C * C + 255) / 256), dim3(256), 0, st, part, gM, C * C, nsplit);
+    hipLaunchKernelGGL(mix_gm_reduce_kernel, dim3((C * C + 63) / 64), dim3(256), 0, st, part, gM, C * C, nsplit);
     return check_launch();
 }
 
