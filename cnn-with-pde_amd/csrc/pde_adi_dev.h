@@ -102,8 +102,13 @@ __device__ __forceinline__ unsigned long long stamp() {
 #define PDE_STAMP_AT(i) do { } while (0)
 #endif
 
-__device__ __forceinline__ float xchg_half(float v) {     // value held by lane ^ 32
-    return __shfl_xor(v, 32, 64);
+// value held by lane ^ 32 (the other half of my line).  v_permlane32_swap (new on gfx950) does it in
+// the VALU; __shfl_xor becomes ds_bpermute_b32, which queues behind the re-layout traffic of the
+// other waves in the LDS pipe, right on the critical path of every solve (the junction).
+__device__ __forceinline__ float xchg_half(float v, int hf) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // r[0] = lo|lo, r[1] = hi|hi
+    return __builtin_bit_cast(float, hf ? r[0] : r[1]);
 }
 
 template <int CTRL>
@@ -339,7 +344,7 @@ __device__ __forceinline__ void solve_fwd(float (&v)[J][M], const float* rec, in
     // junction: x_in = (D_in + e_in * D_in(partner)) / (1 - e_t e_b)
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-        const float other = xchg_half(v[j][M - 1]);
+        const float other = xchg_half(v[j][M - 1], hf);
         v[j][M - 1] = fmaf(e[M - 1], other, v[j][M - 1]) * jn;
     }
     // substitution outwards: x_k = D_k + e_k*x_{k+1}
@@ -473,7 +478,7 @@ __device__ __forceinline__ void solve_adj(float (&r)[J][M], const float* rec, in
     // junction: G_in = (H_in + e_in(partner) H_in(partner)) / (1 - e_t e_b)
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-        const float pv = xchg_half(e[M - 1] * r[j][M - 1]);
+        const float pv = xchg_half(e[M - 1] * r[j][M - 1], hf);
         r[j][M - 1] = (r[j][M - 1] + pv) * jn;
     }
     // G_k = H_k + e_{k+1} G_{k+1};   g_k = inv_k G_k
@@ -518,7 +523,7 @@ __device__ __forceinline__ void state_x(const float (&g)[J][M], float (&x)[J][M]
         }
         if constexpr (MASKED) {
             if (smooth) {                                // transpose of the replicate 3-tap average (x1/3 later)
-                const float gin = xchg_half(gq[M - 1]);
+                const float gin = xchg_half(gq[M - 1], hf);
 #pragma unroll
                 for (int k = 0; k < M; ++k) {
                     float z = (k == 0) ? 2.0f * gq[0] : gq[k] + gq[k - 1];
@@ -688,7 +693,7 @@ __global__ __launch_bounds__(kThreads) void adi_bwd_kernel(SweepArgs a) {
             } else {
                 float xin[J];                             // partner half's innermost state: issue the
 #pragma unroll
-                for (int j = 0; j < J; ++j) xin[j] = xchg_half(x[j][M - 1]);   // exchange now, use it after the solve
+                for (int j = 0; j < J; ++j) xin[j] = xchg_half(x[j][M - 1], hf);   // exchange now, use it after the solve
                 PDE_STAMP_AT(sb + 1);
                 solve_adj<M, J>(r, rec, l, hf);
                 PDE_STAMP_AT(sb + 2);
