@@ -522,7 +522,7 @@ int pde_adi_forward(const PdeAdiDesc* d, const void* u, void* y, const float* al
     sa.G = groups_per_channel(d, kWaves * kJFwd, 16 / kWaves);
     sa.one_eps = 1.0f + d->eps;
     sa.xcd_map = use_xcd_map(d);
-    const size_t lds = (size_t)(2 * kRecFwd + kWaves * kImage) * sizeof(float);
+    const size_t lds = (size_t)(kRing * kRecFwd + kWaves * kImage) * sizeof(float);
     return dispatch_fwd(d, split_of(d), sa, sa.G * d->C, lds, st);
 }
 
@@ -595,7 +595,7 @@ int pde_adi_backward(const PdeAdiDesc* d, const void* gy, const void* y, const v
         fa.in0 = u; fa.in1 = nullptr; fa.out = nullptr; fa.part = nullptr;
         fa.S = Sf;
         fa.G = groups_per_channel(d, kWaves * kJFwd, 16 / kWaves);
-        const size_t lds_f = (size_t)(2 * kRecFwd + kWaves * kImage) * sizeof(float);
+        const size_t lds_f = (size_t)(kRing * kRecFwd + kWaves * kImage) * sizeof(float);
         // the pre-pass stops after sweep Sf-1, which need not be a step boundary: look the axes up
         rc = dispatch_fwd(d, kSplitAny, fa, fa.G * d->C, lds_f, st, false);
         if (rc != PDE_OK) return rc;

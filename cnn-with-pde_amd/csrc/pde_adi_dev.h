@@ -13,6 +13,12 @@ namespace {
 #endif
 constexpr int kWaves = PDE_WAVES;                 // waves per workgroup
 constexpr int kThreads = kWaves * 64;
+constexpr int kRing = 3;                          // coefficient-record ring of the skewed kernels
+#ifndef PDE_SKEW
+#define PDE_SKEW 1
+#endif
+// waves kWaves/2.. run one sweep behind waves 0..kWaves/2-1 (wave w and w + kWaves/2 share a SIMD)
+__device__ __forceinline__ int wave_lag(int wave) { return (PDE_SKEW && wave >= kWaves / 2) ? 1 : 0; }
 
 // Per-launch sweep table read by the sweep kernels with scalar loads (keeping it in the
 // kernel arguments makes hipcc hold all of it in SGPRs and spill them).
@@ -82,7 +88,7 @@ __device__ __forceinline__ void block_to_work(int b, int C, int G, int xcd_map, 
 // that pass, so the kernel waits itself: dma_wait_all() before the barrier that publishes the data.
 // (m0 is not used by anything else in these kernels; gfx9 DS instructions do not need it.)
 __device__ __forceinline__ void lds_dma16(const float* gsrc, float* lds_wave_base) {
-    const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds_wave_base;
+    const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)lds_wave_base);
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds), "v"(gsrc) : "memory");
 }
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -377,6 +383,20 @@ __device__ __forceinline__ void load_planes(const IO* base, int q, int wave, int
     for (int j = 0; j < J; ++j) plane_to_rows<N>(raw[j], T, lane, l, hf, v[j]);
 }
 
+// one plane at a time (fewer registers in flight; used where the caller's own state is large)
+template <int N, int J, typename IO>
+__device__ __forceinline__ void load_planes_seq(const IO* base, int q, int wave, int lane, int l, int hf, int B, int C,
+                                                int c, float* T, float (&v)[J][N / 2]) {
+    constexpr int PPI = kWaves * J;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        float4 raw[Geo<N>::kLoads];
+        const int b = q * PPI + wave * J + j;
+        plane_fetch<N, IO>(base + ((size_t)b * C + c) * (size_t)(N * N), b < B, lane, raw);
+        plane_to_rows<N>(raw, T, lane, l, hf, v[j]);
+    }
+}
+
 template <int N, int J, typename IO>
 __device__ __forceinline__ void store_planes(IO* base, int q, int wave, int lane, int l, int hf, int B, int C, int c,
                                              float* T, const float (&v)[J][N / 2]) {
@@ -395,8 +415,8 @@ template <int N, int J, typename IO, int SPLIT>
 __global__ __launch_bounds__(kThreads) void adi_fwd_kernel(SweepArgs a) {
     constexpr int M = Geo<N>::M;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* cbuf = smem;                                   // [2][kRecFwd]
-    float* tbuf = smem + 2 * kRecFwd;                     // [kWaves][kImage]
+    float* cbuf = smem;                                   // [kRing][kRecFwd]
+    float* tbuf = smem + kRing * kRecFwd;                 // [kWaves][kImage]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hf = lane >> 5, l = lane & 31;
     int c, g;
@@ -408,28 +428,39 @@ __global__ __launch_bounds__(kThreads) void adi_fwd_kernel(SweepArgs a) {
     constexpr int PPI = kWaves * J;                       // planes per workgroup iteration
     const int nchunk = (a.B + PPI - 1) / PPI;
     const size_t plane = (size_t)N * N;
+    // Phase skew (see "skew" in pde_adi.hip): the upper half of the waves runs ONE sweep behind the
+    // lower half, so while one half is in a y sweep (re-layouts: LDS pipe) the other is in an x sweep
+    // (VALU); in lock-step every wave wants the same pipe at the same time.
+    const int lag = wave_lag(wave);
 
     // rows >= N of the wave images are never written: zero them once so idle lanes read zeros
     for (int e = tid; e < kWaves * kImage; e += kThreads) tbuf[e] = 0.f;
     Staged stg;
     stg.r0 = stg.r1 = stg.r2 = stg.r3 = stg.r4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    unsigned n = 0;                                       // running sweep counter (buffer parity)
-    stage_load<kRecFwd>(a.coef + ((size_t)0 * a.C + c) * kRecStride + kG_Inv, tid, stg);
+    // Sweeps are numbered along the whole job of this workgroup (item i = sweep i % S of chunk i / S).
+    // In barrier interval t the lower waves run item t from ring slot t % 3, the upper waves item
+    // t-1 from slot (t-1) % 3, and every thread stages its pieces of item t+1 into slot (t+1) % 3.
+    int cur = 0;                                          // ring slot of my current item
+    auto rec_of = [&](int s) { return a.coef + ((size_t)s * a.C + c) * kRecStride + kG_Inv; };
+    stage_load<kRecFwd>(rec_of(0), tid, stg);
     stage_store<kRecFwd>(cbuf, tid, stg);
     __syncthreads();
+    if (lag) {                                            // interval 0 of the upper waves: staging only
+        stage_load<kRecFwd>(rec_of(a.S > 1 ? 1 : 0), tid, stg);
+        stage_store<kRecFwd>(cbuf + kRecFwd, tid, stg);
+        __syncthreads();
+    }
 
     for (int q = g; q < nchunk; q += a.G) {
         float v[J][M];
         load_planes<N, J, IO>(u, q, wave, lane, l, hf, a.B, a.C, c, T, v);
-        const bool more = q + a.G < nchunk;
         auto sweep = [&](auto AXC, int s) {
             constexpr int AX = decltype(AXC)::value;
-            const int snext = (s + 1 < a.S) ? s + 1 : 0;
-            const bool pre = (s + 1 < a.S) || more;
-#if !(defined(PDE_ABL) && PDE_ABL == 3)
-            if (pre) stage_load<kRecFwd>(a.coef + ((size_t)snext * a.C + c) * kRecStride + kG_Inv, tid, stg);
-#endif
-            const float* rec = cbuf + (n & 1) * kRecFwd;
+            int sp = s + lag + 1;                         // sweep of the item staged in this interval
+            if (sp >= a.S) sp -= a.S;
+            if (sp >= a.S) sp -= a.S;
+            stage_load<kRecFwd>(rec_of(sp), tid, stg);
+            const float* rec = cbuf + cur * kRecFwd;
             const int axs = (AX >= 0) ? AX : tab->axis[s];
             if (axs == PDE_AXIS_Y) relayout_all<N, J>(v, T, l, hf);
             solve_fwd<M, J>(v, rec, l, hf);
@@ -438,11 +469,11 @@ __global__ __launch_bounds__(kThreads) void adi_fwd_kernel(SweepArgs a) {
                 float* slot = a.ckpt + (size_t)ck_slot(a.ck, s) * a.B * a.C * plane;
                 store_planes<N, J, float>(slot, q, wave, lane, l, hf, a.B, a.C, c, T, v);
             }
-#if !(defined(PDE_ABL) && PDE_ABL == 3)
-            if (pre) stage_store<kRecFwd>(cbuf + ((n + 1) & 1) * kRecFwd, tid, stg);
+            int ps = cur + lag + 1;
+            if (ps >= kRing) ps -= kRing;
+            stage_store<kRecFwd>(cbuf + ps * kRecFwd, tid, stg);
             __syncthreads();
-            ++n;
-#endif
+            cur = (cur == kRing - 1) ? 0 : cur + 1;
         };
         if constexpr (SPLIT == kSplitStrang) {
             for (int s = 0; s < a.S; s += 3) {
@@ -460,15 +491,17 @@ __global__ __launch_bounds__(kThreads) void adi_fwd_kernel(SweepArgs a) {
         }
         if (y != nullptr) store_planes<N, J, IO>(y, q, wave, lane, l, hf, a.B, a.C, c, T, v);
     }
+    if (!lag) __syncthreads();                            // the interval in which the upper waves finish
 }
 
 // ---- backward -------------------------------------------------------------------------
 // adjoint two-sided solve (A + eps I)^T g = r on J planes, in place.
+// The coefficient rows (e, inv, jn) are fetched by the caller at the top of the sweep, all at once:
+// fetched where they are used, each array costs its own exposed LDS round trip (3 per sweep, ~300
+// cycles each under load - measured with the interval timeline of tools/read_stamps.py).
 template <int M, int J>
-__device__ __forceinline__ void solve_adj(float (&r)[J][M], const float* rec, int l, int hf) {
-    float e[M];
-    load_half<M>(rec + kB_E + l * kLineStride + hf * kHalfPad, e);
-    const float jn = rec[kB_Jn + l];
+__device__ __forceinline__ void solve_adj(float (&r)[J][M], const float (&e)[M], const float (&inv)[M], float jn,
+                                          int hf) {
     // H_k = r_k + e_{k-1} H_{k-1}
 #pragma unroll
     for (int k = 1; k < M; ++k) {
@@ -487,12 +520,10 @@ __device__ __forceinline__ void solve_adj(float (&r)[J][M], const float* rec, in
 #pragma unroll
         for (int j = 0; j < J; ++j) r[j][k] = fmaf(e[k + 1], r[j][k + 1], r[j][k]);
     }
-    float inv[M];
-    load_half<M>(rec + kB_Inv + l * kLineStride + hf * kHalfPad, inv);       // (1+eps)/den
 #pragma unroll
     for (int k = 0; k < M; ++k) {
 #pragma unroll
-        for (int j = 0; j < J; ++j) r[j][k] *= inv[k];
+        for (int j = 0; j < J; ++j) r[j][k] *= inv[k];                        // inv = (1+eps)/den
     }
 }
 
@@ -503,9 +534,8 @@ __device__ __forceinline__ void solve_adj(float (&r)[J][M], const float* rec, in
 // masked (and un-smoothed) once at the end: do both here, per sweep.
 template <int M, int J, bool MASKED>
 __device__ __forceinline__ void state_x(const float (&g)[J][M], float (&x)[J][M], float (&acc)[M],
-                                        const float (&xin)[J], const float* rec, int l, int hf, int smooth) {
-    float kap[M];
-    load_half<M>(rec + kB_KapX + l * kLineStride + hf * kHalfPad, kap);
+                                        const float (&xin)[J], const float (&kap)[M], const float* rec, int l, int hf,
+                                        int smooth) {
     float msk[MASKED ? M : 1];
     if constexpr (MASKED) load_half<M>(rec + kB_MaskX + l * kLineStride + hf * kHalfPad, msk);
 #pragma unroll
@@ -543,10 +573,8 @@ __device__ __forceinline__ void state_x(const float (&g)[J][M], float (&x)[J][M]
 // same half).
 template <int N, int J, bool MASKED>
 __device__ __forceinline__ void state_y(const float (&g)[J][N / 2], float (&x)[J][N / 2], float (&acc)[N / 2],
-                                        const float* rec, int l, int hf, int smooth) {
+                                        const float (&kap)[N / 2], const float* rec, int l, int hf, int smooth) {
     constexpr int M = N / 2;
-    float kap[M];
-    load_half<M>(rec + kB_KapX + l * kLineStride + hf * kHalfPad, kap);
     float msk[MASKED ? M : 1];
     if constexpr (MASKED) load_half<M>(rec + kB_MaskX + l * kLineStride + hf * kHalfPad, msk);
     const bool edge = (l == 0 || l == N - 1);
@@ -585,16 +613,17 @@ __device__ __forceinline__ void state_y(const float (&g)[J][N / 2], float (&x)[J
 }
 
 // LDS footprint (floats) of the coefficient buffers of the backward kernel.  With a compile-time
-// step pattern the records of a WHOLE STEP are staged at once by LDS-DMA (global_load_lds, no
-// registers, no ds_write) into one of two step buffers, and the workgroup meets at ONE barrier per
-// step instead of one per sweep; records are padded to whole 1-KB DMA pieces.
+// step pattern the records are staged by LDS-DMA (global_load_lds: no registers, no ds_write) into
+// a ring of kRing slots, one record per barrier interval, the upper waves running one sweep behind
+// the lower ones (phase skew, as in the forward kernel); records are padded to whole 1-KB DMA pieces.
 template <bool MASKED, int SPLIT>
 struct BwdStage {
     static constexpr int kSps = SPLIT == kSplitStrang ? 3 : (SPLIT == kSplitLie ? 2 : 1);
     static constexpr bool kStep = SPLIT != kSplitAny;
     static constexpr int kRec = MASKED ? kRecBwdMasked : kRecBwd;
     static constexpr int kRecPad = kStep ? ((kRec / 4 + 63) / 64) * 256 : kRec;
-    static constexpr int kFloats = 2 * kSps * kRecPad;
+    static constexpr int kSlots = 2 * kSps + 1;           // record ring of the pattern kernels
+    static constexpr int kFloats = kStep ? kSlots * kRecPad : 2 * kRecPad;
 };
 
 template <int N, int J, typename IO, bool MASKED, int SPLIT>
@@ -607,7 +636,7 @@ __global__ __launch_bounds__(kThreads) void adi_bwd_kernel(SweepArgs a) {
     if ((as_const(a.varying)[c] != 0) != MASKED) return;  // the other instantiation owns this channel
     const ConstTab tab = as_const(a.tab);
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* cbuf = smem;                                   // [2][SPS][RECP]
+    float* cbuf = smem;                                   // pattern: [kSlots][RECP]; any: [2][REC]
     float* tbuf = smem + ST::kFloats;                     // [kWaves][kImage]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hf = lane >> 5, l = lane & 31;
@@ -628,144 +657,172 @@ __global__ __launch_bounds__(kThreads) void adi_bwd_kernel(SweepArgs a) {
     const int first_x = tab->first_s[0], first_y = tab->first_s[1];
     const float tlast_x = tab->t_last[0], tlast_y = tab->t_last[1];
 
-    // records of the step whose newest sweep is s_hi -> step buffer `buf` (slot r holds sweep s_hi - r)
-    auto dma_step = [&](int buf, int s_hi) {
+    const int lag = ST::kStep ? wave_lag(wave) : 0;
+    // record of sweep s -> ring slot `slot`
+    auto dma_rec = [&](int slot, int s) __attribute__((always_inline)) {
         constexpr int PPR = RECP / 256;                   // 1-KB pieces per record
-        for (int p = wave; p < SPS * PPR; p += kWaves) {
-            const int rr = p / PPR, pp = p % PPR;
-            const int f = pp * 64 + lane;                 // 16-byte index inside the record
-            const float* src = a.coef + ((size_t)(s_hi - rr) * a.C + c) * kRecStride + kBwdOff + 4 * f;
-            float* dst = cbuf + ((size_t)buf * SPS + rr) * RECP + pp * 256;          // wave-uniform
+        for (int p = wave; p < PPR; p += kWaves) {
+            const int f = p * 64 + lane;                  // 16-byte index inside the record
+            const float* src = a.coef + ((size_t)s * a.C + c) * kRecStride + kBwdOff + 4 * f;
+            float* dst = cbuf + (size_t)slot * RECP + p * 256;                       // wave-uniform
             if (f < REC / 4) lds_dma16(src, dst);
         }
     };
-    Staged stg;
-    stg.r0 = stg.r1 = stg.r2 = stg.r3 = stg.r4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    unsigned n = 0;                                       // buffer parity (per step or per sweep)
-    if constexpr (ST::kStep) {
-        dma_step(0, a.S - 1);
-        dma_wait_all();
-    } else {
-        stage_load<REC>(a.coef + ((size_t)(a.S - 1) * a.C + c) * kRecStride + kBwdOff, tid, stg);
-        stage_store<REC>(cbuf, tid, stg);
-    }
-    __syncthreads();
 
-    for (int q = g; q < nchunk; q += a.G) {
-        float r[J][M], x[J][M];
-        load_planes<N, J, IO>(gy, q, wave, lane, l, hf, a.B, a.C, c, T, r);
-        load_planes<N, J, IO>(yy, q, wave, lane, l, hf, a.B, a.C, c, T, x);
-        // The time-weighted sums use summation by parts over the whole processing sequence
-        // (all chunks, sweeps in decreasing time):  sum_i tau_i G_i = sum_i (tau_i - tau_{i+1}) R_i
-        // with R_i the running sum of g.q and tau_{i+1} the time of the next processed sweep of
-        // the same axis (0 after the very last one).  So Ax/Ay double as R and are never reset.
-        const bool more = q + a.G < nchunk;
-#ifdef PDE_STAMP
-        unsigned long long stamps[16];
-        for (int i = 0; i < 16; ++i) stamps[i] = 0;
-#endif
-        auto body = [&](auto AXC, int s, const float* rec, float dts) {
-            constexpr int AX = decltype(AXC)::value;
-            const int axs = (AX >= 0) ? AX : tab->axis[s];
-#ifdef PDE_STAMP
-            const bool stamp_on = (blockIdx.x == 5 && wave == 3 && q == g && s >= 12 && s <= 14);
-            const int sb = (14 - s) * 5;                     // s=14 (x): 0.., s=13 (y): 5.., s=12 (x): 10..
-            PDE_STAMP_AT(sb + 0);
-#endif
-            if (more && s == (axs == PDE_AXIS_Y ? first_y : first_x)) dts -= (axs == PDE_AXIS_Y ? tlast_y : tlast_x);
-            if (axs == PDE_AXIS_Y) {
-                relayout_all<N, J>(r, T, l, hf);
-                PDE_STAMP_AT(sb + 1);
-                solve_adj<M, J>(r, rec, l, hf);
-                PDE_STAMP_AT(sb + 2);
-                relayout_all<N, J>(r, T, l, hf);
-                PDE_STAMP_AT(sb + 3);
+    float r[J][M], x[J][M];
+    int q = g;                                            // chunk of my current item
+    bool more = q + a.G < nchunk;
+    // The time-weighted sums use summation by parts over the whole processing sequence
+    // (all chunks, sweeps in decreasing time):  sum_i tau_i G_i = sum_i (tau_i - tau_{i+1}) R_i
+    // with R_i the running sum of g.q and tau_{i+1} the time of the next processed sweep of
+    // the same axis (0 after the very last one).  So Ax/Ay double as R and are never reset.
+    auto body = [&](auto AXC, int axr, int s, const float* rec, float dts) __attribute__((always_inline)) {
+        constexpr int AX = decltype(AXC)::value;
+        const int axs = (AX >= 0) ? AX : axr;
+        if (more && s == (axs == PDE_AXIS_Y ? first_y : first_x)) dts -= (axs == PDE_AXIS_Y ? tlast_y : tlast_x);
+        float ce[M], cinv[M], ckap[M];
+        const float* crow = rec + l * kLineStride + hf * kHalfPad;
+        const float cjn = rec[kB_Jn + l];
+        if (axs == PDE_AXIS_Y) {
+            relayout_all<N, J>(r, T, l, hf);
+            load_half<M>(crow + kB_E, ce);
+            load_half<M>(crow + kB_Inv, cinv);
+            solve_adj<M, J>(r, ce, cinv, cjn, hf);
+            relayout_all<N, J>(r, T, l, hf);
+            load_half<M>(crow + kB_KapX, ckap);
 #if !(defined(PDE_ABL) && PDE_ABL == 2)
-                state_y<N, J, MASKED>(r, x, Ay, rec, l, hf, a.smooth3);
-                PDE_STAMP_AT(sb + 4);
+            state_y<N, J, MASKED>(r, x, Ay, ckap, rec, l, hf, a.smooth3);
 #else
-                Ay[0] += r[0][0];
+            Ay[0] += r[0][0];
 #endif
-                if (dts != 0.f) {
+            if (dts != 0.f) {
 #pragma unroll
-                    for (int k = 0; k < M; ++k) Ty[k] = fmaf(dts, Ay[k], Ty[k]);
-                }
-            } else {
-                float xin[J];                             // partner half's innermost state: issue the
-#pragma unroll
-                for (int j = 0; j < J; ++j) xin[j] = xchg_half(x[j][M - 1], hf);   // exchange now, use it after the solve
-                PDE_STAMP_AT(sb + 1);
-                solve_adj<M, J>(r, rec, l, hf);
-                PDE_STAMP_AT(sb + 2);
-#if !(defined(PDE_ABL) && PDE_ABL == 2)
-                state_x<M, J, MASKED>(r, x, Ax, xin, rec, l, hf, a.smooth3);
-                PDE_STAMP_AT(sb + 3);
-#else
-                Ax[0] += xin[0] + r[0][0];
-#endif
-                if (dts != 0.f) {
-#pragma unroll
-                    for (int k = 0; k < M; ++k) Tx[k] = fmaf(dts, Ax[k], Tx[k]);
-                }
-            }
-            // x now holds the rebuilt state after sweep s-1; take the checkpoint instead if there is one
-            if (s > 0 && a.ckpt != nullptr && ck_bit(a.ck, s - 1)) {
-                const float* slot = a.ckpt + (size_t)ck_slot(a.ck, s - 1) * a.B * a.C * plane;
-                load_planes<N, J, float>(slot, q, wave, lane, l, hf, a.B, a.C, c, T, x);
-                const float sc = tab->ysc[s - 1];             // true state -> rescaled state of sweep s-1
-#pragma unroll
-                for (int j = 0; j < J; ++j) {
-#pragma unroll
-                    for (int k = 0; k < M; ++k) x[j][k] *= sc;
-                }
-            }
-        };
-        if constexpr (ST::kStep) {
-            for (int s = a.S - 1; s >= 0; s -= SPS) {
-                const int nxt = (s - SPS >= 0) ? s - SPS : (more ? a.S - 1 : -1);
-                if (nxt >= 0) dma_step((n + 1) & 1, nxt);     // lands during this step, read in the next
-                const float* base = cbuf + (size_t)(n & 1) * SPS * RECP;
-                const float d0 = tab->dts[s], d1 = tab->dts[s - 1];          // issued together, up front
-                if constexpr (SPLIT == kSplitStrang) {
-                    const float d2 = tab->dts[s - 2];
-                    body(std::integral_constant<int, PDE_AXIS_X>{}, s, base, d0);
-                    body(std::integral_constant<int, PDE_AXIS_Y>{}, s - 1, base + RECP, d1);
-                    body(std::integral_constant<int, PDE_AXIS_X>{}, s - 2, base + 2 * RECP, d2);
-                } else {
-                    body(std::integral_constant<int, PDE_AXIS_Y>{}, s, base, d0);
-                    body(std::integral_constant<int, PDE_AXIS_X>{}, s - 1, base + RECP, d1);
-                }
-#ifdef PDE_STAMP
-                if (blockIdx.x == 5 && wave == 3 && q == g && s == 14) stamps[15] = stamp();
-#endif
-                dma_wait_all();                           // my DMA pieces (issued a whole step ago) have landed
-                __syncthreads();                          // ... everyone's have, and everyone is done reading
-#ifdef PDE_STAMP
-                if (blockIdx.x == 5 && wave == 3 && q == g && s == 14 && lane == 0) {
-                    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.dbg);
-                    for (int i = 0; i < 16; ++i) dbg[i] = stamps[i];
-                    dbg[16] = stamp();
-                }
-#endif
-                ++n;
+                for (int k = 0; k < M; ++k) Ty[k] = fmaf(dts, Ay[k], Ty[k]);
             }
         } else {
-            for (int s = a.S - 1; s >= 0; --s) {
-                const int snext = (s > 0) ? s - 1 : a.S - 1;
-                const bool pre = (s > 0) || more;
-                if (pre) stage_load<REC>(a.coef + ((size_t)snext * a.C + c) * kRecStride + kBwdOff, tid, stg);
-                body(std::integral_constant<int, -1>{}, s, cbuf + (n & 1) * RECP, tab->dts[s]);
-                if (pre) stage_store<REC>(cbuf + ((n + 1) & 1) * RECP, tid, stg);
-                __syncthreads();
-                ++n;
+            float xin[J];                                 // partner half's innermost state: issue the
+#pragma unroll
+            for (int j = 0; j < J; ++j) xin[j] = xchg_half(x[j][M - 1], hf);   // exchange now, use it after the solve
+            load_half<M>(crow + kB_E, ce);
+            load_half<M>(crow + kB_Inv, cinv);
+            solve_adj<M, J>(r, ce, cinv, cjn, hf);
+            load_half<M>(crow + kB_KapX, ckap);
+#if !(defined(PDE_ABL) && PDE_ABL == 2)
+            state_x<M, J, MASKED>(r, x, Ax, xin, ckap, rec, l, hf, a.smooth3);
+#else
+            Ax[0] += xin[0] + r[0][0];
+#endif
+            if (dts != 0.f) {
+#pragma unroll
+                for (int k = 0; k < M; ++k) Tx[k] = fmaf(dts, Ax[k], Tx[k]);
             }
         }
+        // x now holds the rebuilt state after sweep s-1; take the checkpoint instead if there is one
+        if (s > 0 && a.ckpt != nullptr && ck_bit(a.ck, s - 1)) {
+            const float* slot = a.ckpt + (size_t)ck_slot(a.ck, s - 1) * a.B * a.C * plane;
+            load_planes<N, J, float>(slot, q, wave, lane, l, hf, a.B, a.C, c, T, x);
+            const float sc = tab->ysc[s - 1];             // true state -> rescaled state of sweep s-1
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+#pragma unroll
+                for (int k = 0; k < M; ++k) x[j][k] *= sc;
+            }
+        }
+    };
+    auto chunk_in = [&]() __attribute__((always_inline)) {
+        load_planes_seq<N, J, IO>(gy, q, wave, lane, l, hf, a.B, a.C, c, T, r);
+        load_planes_seq<N, J, IO>(yy, q, wave, lane, l, hf, a.B, a.C, c, T, x);
+    };
+    auto chunk_out = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < J; ++j) {
 #pragma unroll
             for (int k = 0; k < M; ++k) r[j][k] *= a.gu_scale;     // undo the (1+eps) carried per sweep
         }
         store_planes<N, J, IO>(gu, q, wave, lane, l, hf, a.B, a.C, c, T, r);
+    };
+
+    if constexpr (ST::kStep) {
+        // Sweeps are numbered along the whole job of this workgroup in processing order (item i = sweep
+        // S-1 - i % S of my chunk i / S).  A barrier interval covers one time step (SPS items): the lower
+        // waves run items SPS*t .. SPS*t+SPS-1, the upper waves the same window shifted back by one item
+        // (phase skew: they are in an x sweep, VALU, while the lower ones are in the y sweep, LDS
+        // re-layouts, and the other way round), and everybody's DMA brings in the records of the next
+        // interval.  Live at any time: 2*SPS+1 consecutive items = the ring (slot = item % kSlots).
+        constexpr int kSlots = ST::kSlots;
+        const int nmine = (nchunk - g + a.G - 1) / a.G;                  // my chunks: g, g+G, ...
+        const int ntot = nmine * a.S;
+        const int nint = ntot / SPS + 1;
+        int dslot = 0, dsw = a.S - 1, ditem = 0;                         // next record to fetch
+        auto dma_next = [&]() __attribute__((always_inline)) {
+#pragma unroll 1
+            for (int i = 0; i < SPS; ++i) {
+                if (ditem < ntot) dma_rec(dslot, dsw);
+                ++ditem;
+                dslot = (dslot + 1 == kSlots) ? 0 : dslot + 1;
+                dsw = (dsw == 0) ? a.S - 1 : dsw - 1;
+            }
+        };
+        dma_next();
+        dma_wait_all();
+        __syncthreads();
+        // The two halves run the same loop with their own compile-time pattern (position of an item
+        // inside its time step -> axis, chunk boundaries): x y x | x y x for the lower waves, the same
+        // sequence cut one item earlier for the upper ones.
+        auto run = [&](auto LAGC) __attribute__((always_inline)) {
+            constexpr int LAG = decltype(LAGC)::value;
+            int item = -LAG, s = a.S - 1, slot = 0;       // my next item, its sweep, its ring slot
+#pragma unroll 1
+            for (int t = 0; t < nint; ++t) {
+                dma_next();
+                sfor<0, SPS>([&](auto IC) __attribute__((always_inline)) {
+                    constexpr int pos = (decltype(IC)::value - LAG + SPS) % SPS;     // 0: newest sweep of a step
+                    constexpr int AX = ((SPS - 1 - pos) == 1) ? PDE_AXIS_Y : PDE_AXIS_X;
+                    if (item >= 0 && item < ntot) {
+                        if constexpr (pos == 0) {
+                            if (s == a.S - 1) chunk_in();
+                        }
+                        body(std::integral_constant<int, AX>{}, AX, s, cbuf + (size_t)slot * RECP, tab->dts[s]);
+                        if constexpr (pos == SPS - 1) {
+                            if (s == 0) {
+                                chunk_out();
+                                q += a.G;
+                                more = q + a.G < nchunk;
+                                s = a.S;
+                            }
+                        }
+                        --s;
+                        slot = (slot + 1 == kSlots) ? 0 : slot + 1;
+                    }
+                    ++item;
+                });
+                dma_wait_all();                           // my DMA pieces (issued a whole step ago) have landed
+                __syncthreads();                          // ... everyone's have, and everyone is done reading
+            }
+        };
+        if (lag) run(std::integral_constant<int, 1>{});
+        else run(std::integral_constant<int, 0>{});
+    } else {
+        Staged stg;
+        stg.r0 = stg.r1 = stg.r2 = stg.r3 = stg.r4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        unsigned n = 0;                                   // buffer parity
+        stage_load<REC>(a.coef + ((size_t)(a.S - 1) * a.C + c) * kRecStride + kBwdOff, tid, stg);
+        stage_store<REC>(cbuf, tid, stg);
+        __syncthreads();
+        for (; q < nchunk; q += a.G) {
+            more = q + a.G < nchunk;
+            chunk_in();
+            for (int s = a.S - 1; s >= 0; --s) {
+                const int snext = (s > 0) ? s - 1 : a.S - 1;
+                const bool pre = (s > 0) || more;
+                if (pre) stage_load<REC>(a.coef + ((size_t)snext * a.C + c) * kRecStride + kBwdOff, tid, stg);
+                body(std::integral_constant<int, -1>{}, tab->axis[s], s, cbuf + (n & 1) * RECP, tab->dts[s]);
+                if (pre) stage_store<REC>(cbuf + ((n + 1) & 1) * RECP, tid, stg);
+                __syncthreads();
+                ++n;
+            }
+            chunk_out();
+        }
     }
 
     // deterministic reduction of the four sums over the waves of this workgroup

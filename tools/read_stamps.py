@@ -23,8 +23,12 @@ lib = L.load()
 d = F_._make_desc(512, 64, 32, 0, [s for st in P.adi_schedule(0.001, 1, 1, 10) for s in st], False, 10.0, 1e-6)
 total = lib.pde_adi_backward_workspace_bytes(C.byref(d), 0)
 off = total - 512 - 0          # diagnostics scratch sits right before the (empty) checkpoint area
-st = ws[off:off + 17 * 8].cpu().view(torch.int64).tolist()
-names = {0: "x-sweep s=14", 5: "y-sweep s=13", 10: "x-sweep s=12"}
-for b in (0, 5, 10):
-    print(names[b], [st[b + i + 1] - st[b + i] for i in range(4) if st[b + i + 1] and st[b + i]])
-print("step total", st[15] - st[0], "barrier wait", st[16] - st[15])
+st = ws[off:off + 48 * 8].cpu().view(torch.int64).tolist()
+# timeline of sweeps 20..15 (processing order) for a lower wave (3) and an upper wave (7) of one workgroup
+t0 = min(v for v in st if v > 0)
+for w, base in (("wave3 (lower)", 0), ("wave7 (upper, one sweep behind)", 24)):
+    print(w)
+    for i in range(6):
+        e, b, d, s_ = (st[base + 4 * i + k] - t0 for k in range(4))
+        ax = "x" if (20 - i) % 3 != 1 else "y"
+        print(f"  sweep {20 - i} ({ax}): enter {e:6d}  body {b - e:5d}  dma-wait {d - b:4d}  barrier {s_ - d:5d}  -> leaves at {s_:6d}")
