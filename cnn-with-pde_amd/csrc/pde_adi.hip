@@ -16,9 +16,14 @@
 //     coefficients and meet in one cross-lane exchange, so a 64-wide wave is exactly
 //     32 lines x 2 halves;
 //   * the factorisation depends on (sweep, channel, line) only, never on the sample:
-//     a small kernel computes it once per call, the sweep kernels stage one record
-//     per sweep into LDS (double buffered, one barrier per sweep) and all waves of a
-//     workgroup — which share a channel — read it from there;
+//     a small kernel computes it once per call, the sweep kernels bring one record per
+//     sweep into a small LDS ring (forward: through registers, 3 slots, one barrier per
+//     sweep; backward: LDS-DMA, 2*steps+1 slots, one barrier per TIME STEP) and all
+//     waves of a workgroup — which share a channel — read it from there;
+//   * "skew": the upper half of the waves of a workgroup runs one sweep behind the lower
+//     half (its window of the ring is shifted back by one record), so that the halves
+//     are never both in the y sweep — whose re-layouts load the LDS pipe — at the same
+//     time;
 //   * x <-> y re-layout goes through a wave-private LDS image, 4 B written and read
 //     per element, no workgroup barrier;
 //   * backward: adjoint two-sided solves; the states needed by the coefficient
@@ -27,6 +32,12 @@
 //     y-direction second difference is taken across lanes with DPP), only the adjoint
 //     is re-laid out.  Parameter gradients are accumulated over the batch in registers
 //     and reduced deterministically (no float atomics).
+//   * what bounds the kernels (profiles/README.md): VALU issue.  A wave64 fp32 VALU
+//     instruction occupies its SIMD for 4 cycles, v_pk_*_f32 for 8 (same FLOP rate;
+//     tools/ubench), and the recurrences need ~10 (forward) / ~26 (backward) of them per
+//     element and time step, far more than the 8 / 12 bytes per element the tensors
+//     cost in HBM.  The two planes of a lane are written as a pair (Pack<2>) so that the
+//     packed form stays one flag away (make PACK=1); it measured 4 % slower.
 #include "pde_adi_dev.h"
 #include "pde_adi_launch.h"
 

@@ -124,6 +124,45 @@ __device__ __forceinline__ float dpp_move(float v) {
 constexpr int kDppWaveShl1 = 0x130;   // lane i <- lane i+1
 constexpr int kDppWaveShr1 = 0x138;   // lane i <- lane i-1
 
+// ---- the J planes of a lane as one packed value -----------------------------------------------
+// A wave64 fp32 VALU instruction issues in 4 cycles on gfx950 (16 lanes per cycle per SIMD;
+// tools/ubench/pk_bench.hip), and v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 do TWO fp32 per lane in
+// the same 4 cycles.  The two planes a lane works on go through identical arithmetic with shared
+// coefficients, so they live in one 64-bit register pair (.x = plane 0, .y = plane 1) and every
+// recurrence step is one packed instruction; the coefficient is broadcast by op_sel, not copied.
+#ifndef PDE_PACK
+#define PDE_PACK 1
+#endif
+#if PDE_PACK
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f v2_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+#else
+// comparison build (make PACK=0): the same code on two scalar registers per pair
+struct v2f { float x, y; };
+__device__ __forceinline__ v2f operator+(v2f a, v2f b) { return v2f{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ v2f operator-(v2f a, v2f b) { return v2f{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ v2f operator*(v2f a, v2f b) { return v2f{a.x * b.x, a.y * b.y}; }
+__device__ __forceinline__ v2f operator-(v2f a) { return v2f{-a.x, -a.y}; }
+__device__ __forceinline__ v2f v2_fma(v2f a, v2f b, v2f c) { return v2f{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
+#endif
+template <int J> struct Pack;
+template <> struct Pack<1> { using P = float; };
+template <> struct Pack<2> { using P = v2f; };
+template <int C> __device__ __forceinline__ float pk_get(float p) { return p; }
+template <int C> __device__ __forceinline__ float pk_get(v2f p) { return C ? p.y : p.x; }
+template <int C> __device__ __forceinline__ void pk_set(float& p, float v) { p = v; }
+template <int C> __device__ __forceinline__ void pk_set(v2f& p, float v) { if (C) p.y = v; else p.x = v; }
+__device__ __forceinline__ float pk_fma(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return v2_fma(a, b, c); }
+template <class P> __device__ __forceinline__ P pk_bc(float s);
+template <> __device__ __forceinline__ float pk_bc<float>(float s) { return s; }
+template <> __device__ __forceinline__ v2f pk_bc<v2f>(float s) { return v2f{s, s}; }
+__device__ __forceinline__ float pk_hsum(float p) { return p; }
+__device__ __forceinline__ float pk_hsum(v2f p) { return p.x + p.y; }
+// per-component map (cross-lane moves have no packed form)
+template <class F> __device__ __forceinline__ float pk_map(float p, F&& f) { return f(p); }
+template <class F> __device__ __forceinline__ v2f pk_map(v2f p, F&& f) { return v2f{f(p.x), f(p.y)}; }
+
 // Stage COUNT floats of a coefficient record global -> registers -> LDS: up to three 16-byte
 // pieces per thread, held in plain locals of the kernel (a struct here ends up in scratch).
 struct Staged { float4 r0, r1, r2, r3, r4; };
@@ -218,9 +257,9 @@ __device__ __forceinline__ int pair_slot(int row, int w, bool& swapped) {
     return row * kLineStride + (swapped ? kHalfPad + (N - 2 - w) : w);
 }
 
-template <int N>
+template <int N, int C, class P>
 __device__ __forceinline__ void plane_to_rows(const float4 (&q)[Geo<N>::kLoads], float* T, int lane, int l, int hf,
-                                              float (&v)[Geo<N>::M]) {
+                                              P (&v)[Geo<N>::M]) {
     constexpr int M = Geo<N>::M;
 #pragma unroll
     for (int i = 0; i < Geo<N>::kLoads; ++i) {
@@ -238,16 +277,16 @@ __device__ __forceinline__ void plane_to_rows(const float4 (&q)[Geo<N>::kLoads],
 #pragma unroll
     for (int i = 0; i < (M + 3) / 4; ++i) {
         const float4 x = *reinterpret_cast<const float4*>(src + 4 * i);
-        v[4 * i] = x.x;
-        if (4 * i + 1 < M) v[4 * i + 1] = x.y;
-        if (4 * i + 2 < M) v[4 * i + 2] = x.z;
-        if (4 * i + 3 < M) v[4 * i + 3] = x.w;
+        pk_set<C>(v[4 * i], x.x);
+        if (4 * i + 1 < M) pk_set<C>(v[4 * i + 1], x.y);
+        if (4 * i + 2 < M) pk_set<C>(v[4 * i + 2], x.z);
+        if (4 * i + 3 < M) pk_set<C>(v[4 * i + 3], x.w);
     }
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int N, typename IO>
-__device__ __forceinline__ void rows_to_plane(const float (&v)[Geo<N>::M], float* T, int lane, int l, int hf,
+template <int N, int C, typename IO, class P>
+__device__ __forceinline__ void rows_to_plane(const P (&v)[Geo<N>::M], float* T, int lane, int l, int hf,
                                               IO* gp, bool valid) {
     constexpr int M = Geo<N>::M;
     if (l < N) {
@@ -255,10 +294,10 @@ __device__ __forceinline__ void rows_to_plane(const float (&v)[Geo<N>::M], float
 #pragma unroll
         for (int i = 0; i < (M + 3) / 4; ++i) {
             float4 x;
-            x.x = v[4 * i];
-            x.y = (4 * i + 1 < M) ? v[4 * i + 1] : 0.f;
-            x.z = (4 * i + 2 < M) ? v[4 * i + 2] : 0.f;
-            x.w = (4 * i + 3 < M) ? v[4 * i + 3] : 0.f;
+            x.x = pk_get<C>(v[4 * i]);
+            x.y = (4 * i + 1 < M) ? pk_get<C>(v[4 * i + 1]) : 0.f;
+            x.z = (4 * i + 2 < M) ? pk_get<C>(v[4 * i + 2]) : 0.f;
+            x.w = (4 * i + 3 < M) ? pk_get<C>(v[4 * i + 3]) : 0.f;
             *reinterpret_cast<float4*>(dst + 4 * i) = x;
         }
     }
@@ -285,8 +324,8 @@ __device__ __forceinline__ void rows_to_plane(const float (&v)[Geo<N>::M], float
 // The image used here is private to this exchange, so its rows and its columns are both kept
 // in half order (row index hf*M + k, column index half_pos): every access is then
 // lane base + compile-time offset.
-template <int N>
-__device__ __forceinline__ void relayout(float (&v)[Geo<N>::M], float* T, int l, int hf) {
+template <int N, int C, class P>
+__device__ __forceinline__ void relayout(P (&v)[Geo<N>::M], float* T, int l, int hf) {
     constexpr int M = Geo<N>::M;
 #if defined(PDE_ABL) && PDE_ABL == 1
     return;                                   // ablation: no re-layout (results wrong, timing only)
@@ -295,7 +334,7 @@ __device__ __forceinline__ void relayout(float (&v)[Geo<N>::M], float* T, int l,
         const int mypos = (l < M) ? l : kHalfPad + (N - 1 - l);
         float* dst = T + hf * M * kLineStride + mypos;
 #pragma unroll
-        for (int k = 0; k < M; ++k) dst[k * kLineStride] = v[k];
+        for (int k = 0; k < M; ++k) dst[k * kLineStride] = pk_get<C>(v[k]);
     }
     __builtin_amdgcn_wave_barrier();
     const int myrow = (l < M) ? l : M + (N - 1 - l);
@@ -303,20 +342,19 @@ __device__ __forceinline__ void relayout(float (&v)[Geo<N>::M], float* T, int l,
 #pragma unroll
     for (int i = 0; i < (M + 3) / 4; ++i) {
         const float4 x = *reinterpret_cast<const float4*>(src + 4 * i);
-        v[4 * i] = x.x;
-        if (4 * i + 1 < M) v[4 * i + 1] = x.y;
-        if (4 * i + 2 < M) v[4 * i + 2] = x.z;
-        if (4 * i + 3 < M) v[4 * i + 3] = x.w;
+        pk_set<C>(v[4 * i], x.x);
+        if (4 * i + 1 < M) pk_set<C>(v[4 * i + 1], x.y);
+        if (4 * i + 2 < M) pk_set<C>(v[4 * i + 2], x.z);
+        if (4 * i + 3 < M) pk_set<C>(v[4 * i + 3], x.w);
     }
     __builtin_amdgcn_wave_barrier();
 }
 
 // (A two-planes-at-once variant with ds_write_b64 was measured and dropped: 3-6 % slower in both
-// kernels; the LDS store path gains nothing from 8-byte stores in this scatter.)
+// kernels and 82 vs 67 CU cycles per plane in tools/ubench/relayout_bench.hip.)
 template <int N, int J>
-__device__ __forceinline__ void relayout_all(float (&v)[J][Geo<N>::M], float* T, int l, int hf) {
-#pragma unroll
-    for (int j = 0; j < J; ++j) relayout<N>(v[j], T, l, hf);
+__device__ __forceinline__ void relayout_all(typename Pack<J>::P (&v)[Geo<N>::M], float* T, int l, int hf) {
+    sfor<0, J>([&](auto CC) __attribute__((always_inline)) { relayout<N, decltype(CC)::value>(v, T, l, hf); });
 }
 
 template <int M>
@@ -333,7 +371,8 @@ __device__ __forceinline__ void load_half(const float* src, float (&dst)[M]) {
 
 // ---- forward: (A + eps I) x = d on J planes, two-sided ---------------------------------
 template <int M, int J>
-__device__ __forceinline__ void solve_fwd(float (&v)[J][M], const float* rec, int l, int hf) {
+__device__ __forceinline__ void solve_fwd(typename Pack<J>::P (&v)[M], const float* rec, int l, int hf) {
+    using P = typename Pack<J>::P;
     float e[M], inv[M];
     load_half<M>(rec + kF_E + l * kLineStride + hf * kHalfPad, e);
     load_half<M>(rec + kF_Inv + l * kLineStride + hf * kHalfPad, inv);
@@ -341,24 +380,17 @@ __device__ __forceinline__ void solve_fwd(float (&v)[J][M], const float* rec, in
     // elimination from my end inwards: D_k = d_k*inv_k + e_k*D_{k-1}
 #pragma unroll
     for (int k = 0; k < M; ++k) {
-#pragma unroll
-        for (int j = 0; j < J; ++j) {
-            const float t = v[j][k] * inv[k];
-            v[j][k] = (k == 0) ? t : fmaf(e[k], v[j][k - 1], t);
-        }
+        const P t = v[k] * pk_bc<P>(inv[k]);
+        v[k] = (k == 0) ? t : pk_fma(pk_bc<P>(e[k]), v[k - 1], t);
     }
     // junction: x_in = (D_in + e_in * D_in(partner)) / (1 - e_t e_b)
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-        const float other = xchg_half(v[j][M - 1], hf);
-        v[j][M - 1] = fmaf(e[M - 1], other, v[j][M - 1]) * jn;
+    {
+        const P other = pk_map(v[M - 1], [&](float z) { return xchg_half(z, hf); });
+        v[M - 1] = pk_fma(pk_bc<P>(e[M - 1]), other, v[M - 1]) * pk_bc<P>(jn);
     }
     // substitution outwards: x_k = D_k + e_k*x_{k+1}
 #pragma unroll
-    for (int k = M - 2; k >= 0; --k) {
-#pragma unroll
-        for (int j = 0; j < J; ++j) v[j][k] = fmaf(e[k], v[j][k + 1], v[j][k]);
-    }
+    for (int k = M - 2; k >= 0; --k) v[k] = pk_fma(pk_bc<P>(e[k]), v[k + 1], v[k]);
 }
 
 __device__ __forceinline__ int ck_slot(const unsigned long long (&ck)[2], int s) {
@@ -371,7 +403,7 @@ __device__ __forceinline__ int ck_bit(const unsigned long long (&ck)[2], int s) 
 
 template <int N, int J, typename IO>
 __device__ __forceinline__ void load_planes(const IO* base, int q, int wave, int lane, int l, int hf, int B, int C,
-                                            int c, float* T, float (&v)[J][N / 2]) {
+                                            int c, float* T, typename Pack<J>::P (&v)[N / 2]) {
     constexpr int PPI = kWaves * J;
     float4 raw[J][Geo<N>::kLoads];
 #pragma unroll
@@ -379,33 +411,34 @@ __device__ __forceinline__ void load_planes(const IO* base, int q, int wave, int
         const int b = q * PPI + wave * J + j;
         plane_fetch<N, IO>(base + ((size_t)b * C + c) * (size_t)(N * N), b < B, lane, raw[j]);
     }
-#pragma unroll
-    for (int j = 0; j < J; ++j) plane_to_rows<N>(raw[j], T, lane, l, hf, v[j]);
+    sfor<0, J>([&](auto CC) __attribute__((always_inline)) {
+        plane_to_rows<N, decltype(CC)::value>(raw[decltype(CC)::value], T, lane, l, hf, v);
+    });
 }
 
 // one plane at a time (fewer registers in flight; used where the caller's own state is large)
 template <int N, int J, typename IO>
 __device__ __forceinline__ void load_planes_seq(const IO* base, int q, int wave, int lane, int l, int hf, int B, int C,
-                                                int c, float* T, float (&v)[J][N / 2]) {
+                                                int c, float* T, typename Pack<J>::P (&v)[N / 2]) {
     constexpr int PPI = kWaves * J;
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
+    sfor<0, J>([&](auto CC) __attribute__((always_inline)) {
+        constexpr int j = decltype(CC)::value;
         float4 raw[Geo<N>::kLoads];
         const int b = q * PPI + wave * J + j;
         plane_fetch<N, IO>(base + ((size_t)b * C + c) * (size_t)(N * N), b < B, lane, raw);
-        plane_to_rows<N>(raw, T, lane, l, hf, v[j]);
-    }
+        plane_to_rows<N, j>(raw, T, lane, l, hf, v);
+    });
 }
 
 template <int N, int J, typename IO>
 __device__ __forceinline__ void store_planes(IO* base, int q, int wave, int lane, int l, int hf, int B, int C, int c,
-                                             float* T, const float (&v)[J][N / 2]) {
+                                             float* T, const typename Pack<J>::P (&v)[N / 2]) {
     constexpr int PPI = kWaves * J;
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
+    sfor<0, J>([&](auto CC) __attribute__((always_inline)) {
+        constexpr int j = decltype(CC)::value;
         const int b = q * PPI + wave * J + j;
-        rows_to_plane<N, IO>(v[j], T, lane, l, hf, base + ((size_t)b * C + c) * (size_t)(N * N), b < B);
-    }
+        rows_to_plane<N, j, IO>(v, T, lane, l, hf, base + ((size_t)b * C + c) * (size_t)(N * N), b < B);
+    });
 }
 
 // ---- forward kernel ---------------------------------------------------------------------
@@ -452,7 +485,7 @@ __global__ __launch_bounds__(kThreads) void adi_fwd_kernel(SweepArgs a) {
     }
 
     for (int q = g; q < nchunk; q += a.G) {
-        float v[J][M];
+        typename Pack<J>::P v[M];
         load_planes<N, J, IO>(u, q, wave, lane, l, hf, a.B, a.C, c, T, v);
         auto sweep = [&](auto AXC, int s) {
             constexpr int AX = decltype(AXC)::value;
@@ -495,37 +528,31 @@ __global__ __launch_bounds__(kThreads) void adi_fwd_kernel(SweepArgs a) {
 }
 
 // ---- backward -------------------------------------------------------------------------
-// adjoint two-sided solve (A + eps I)^T g = r on J planes, in place.
-// The coefficient rows (e, inv, jn) are fetched by the caller at the top of the sweep, all at once:
-// fetched where they are used, each array costs its own exposed LDS round trip (3 per sweep, ~300
-// cycles each under load - measured with the interval timeline of tools/read_stamps.py).
+// The coefficient rows (e, inv, jn) are fetched by the caller.
+// adjoint two-sided solve (A + eps I)^T g = r on the J planes of a lane, in place.
 template <int M, int J>
-__device__ __forceinline__ void solve_adj(float (&r)[J][M], const float (&e)[M], const float (&inv)[M], float jn,
-                                          int hf) {
+__device__ __forceinline__ void solve_adj(typename Pack<J>::P (&r)[M], const float (&e)[M], const float (&inv)[M],
+                                          float jn, int hf) {
+    using P = typename Pack<J>::P;
     // H_k = r_k + e_{k-1} H_{k-1}
 #pragma unroll
-    for (int k = 1; k < M; ++k) {
-#pragma unroll
-        for (int j = 0; j < J; ++j) r[j][k] = fmaf(e[k - 1], r[j][k - 1], r[j][k]);
-    }
+    for (int k = 1; k < M; ++k) r[k] = pk_fma(pk_bc<P>(e[k - 1]), r[k - 1], r[k]);
     // junction: G_in = (H_in + e_in(partner) H_in(partner)) / (1 - e_t e_b)
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-        const float pv = xchg_half(e[M - 1] * r[j][M - 1], hf);
-        r[j][M - 1] = (r[j][M - 1] + pv) * jn;
+    {
+        const P mine = r[M - 1] * pk_bc<P>(e[M - 1]);
+        const P pv = pk_map(mine, [&](float z) { return xchg_half(z, hf); });
+        r[M - 1] = (r[M - 1] + pv) * pk_bc<P>(jn);
     }
     // G_k = H_k + e_{k+1} G_{k+1};   g_k = inv_k G_k
 #pragma unroll
-    for (int k = M - 2; k >= 0; --k) {
+    for (int k = M - 2; k >= 0; --k) r[k] = pk_fma(pk_bc<P>(e[k + 1]), r[k + 1], r[k]);
 #pragma unroll
-        for (int j = 0; j < J; ++j) r[j][k] = fmaf(e[k + 1], r[j][k + 1], r[j][k]);
-    }
-#pragma unroll
-    for (int k = 0; k < M; ++k) {
-#pragma unroll
-        for (int j = 0; j < J; ++j) r[j][k] *= inv[k];                        // inv = (1+eps)/den
-    }
+    for (int k = 0; k < M; ++k) r[k] = r[k] * pk_bc<P>(inv[k]);             // inv = (1+eps)/den
 }
+
+// acc += sum over the planes of a lane of g*q (the accumulators are shared by the planes)
+__device__ __forceinline__ float acc_gq(float acc, float g, float q) { return fmaf(g, q, acc); }
+__device__ __forceinline__ float acc_gq(float acc, v2f g, v2f q) { return fmaf(g.y, q.y, fmaf(g.x, q.x, acc)); }
 
 // After an x sweep has been undone on the adjoint (g in r[]), use the sweep's OUTPUT state
 // x to (1) add g.(Lx) to the coefficient-gradient sums, (2) rebuild the sweep's input
@@ -533,47 +560,60 @@ __device__ __forceinline__ void solve_adj(float (&r)[J][M], const float (&e)[M],
 // MASKED: the clamp mask of this channel changes with time, so the sum over sweeps cannot be
 // masked (and un-smoothed) once at the end: do both here, per sweep.
 template <int M, int J, bool MASKED>
-__device__ __forceinline__ void state_x(const float (&g)[J][M], float (&x)[J][M], float (&acc)[M],
-                                        const float (&xin)[J], const float (&kap)[M], const float* rec, int l, int hf,
-                                        int smooth) {
+__device__ __forceinline__ void state_x(const typename Pack<J>::P (&g)[M], typename Pack<J>::P (&x)[M],
+                                        float (&acc)[M], typename Pack<J>::P xin, const float (&kap)[M],
+                                        const float* rec, int l, int hf, int smooth) {
+    using P = typename Pack<J>::P;
     float msk[MASKED ? M : 1];
     if constexpr (MASKED) load_half<M>(rec + kB_MaskX + l * kLineStride + hf * kHalfPad, msk);
+    P gq[MASKED ? M : 1];
+    P xo_next = xin;                                     // inner neighbour of k = M-1 (fetched before the solve)
 #pragma unroll
-    for (int j = 0; j < J; ++j) {
-        float gq[MASKED ? M : 1];
-        float xo_next = xin[j];                          // inner neighbour of k = M-1 (fetched before the solve)
+    for (int k = M - 1; k >= 0; --k) {
+        const P xo = x[k];
+        P q;
+        if (k == 0) q = xo - xo_next;
+        else q = pk_fma(pk_bc<P>(2.0f), xo, -x[k - 1]) - xo_next;
+        if constexpr (MASKED) gq[k] = g[k] * q;
+        else acc[k] = acc_gq(acc[k], g[k], q);
+        x[k] = pk_fma(pk_bc<P>(kap[k]), q, xo);
+        xo_next = xo;
+    }
+    if constexpr (MASKED) {
+        if (smooth) {                                    // transpose of the replicate 3-tap average (x1/3 later)
+            const P gin = pk_map(gq[M - 1], [&](float z) { return xchg_half(z, hf); });
 #pragma unroll
-        for (int k = M - 1; k >= 0; --k) {
-            const float xo = x[j][k];
-            float q = (k == 0) ? xo - xo_next : fmaf(2.0f, xo, -x[j][k - 1]) - xo_next;
-            if constexpr (MASKED) gq[k] = g[j][k] * q;
-            else acc[k] = fmaf(g[j][k], q, acc[k]);
-            x[j][k] = fmaf(kap[k], q, xo);
-            xo_next = xo;
-        }
-        if constexpr (MASKED) {
-            if (smooth) {                                // transpose of the replicate 3-tap average (x1/3 later)
-                const float gin = xchg_half(gq[M - 1], hf);
-#pragma unroll
-                for (int k = 0; k < M; ++k) {
-                    float z = (k == 0) ? 2.0f * gq[0] : gq[k] + gq[k - 1];
-                    z += (k < M - 1) ? gq[k + 1] : gin;
-                    acc[k] = fmaf(msk[k], z, acc[k]);
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < M; ++k) acc[k] = fmaf(msk[k], gq[k], acc[k]);
+            for (int k = 0; k < M; ++k) {
+                P z = (k == 0) ? pk_bc<P>(2.0f) * gq[0] : gq[k] + gq[k - 1];
+                z = z + ((k < M - 1) ? gq[k + 1] : gin);
+                acc[k] = fmaf(msk[k], pk_hsum(z), acc[k]);
             }
+        } else {
+#pragma unroll
+            for (int k = 0; k < M; ++k) acc[k] = fmaf(msk[k], pk_hsum(gq[k]), acc[k]);
         }
     }
+}
+
+// q -= [h>0] x(row h-1) + [h<N-1] x(row h+1): the neighbour rows are the neighbour lanes; the DPP
+// shift rides on the fmac (src0 = shifted x, 0 shifted in at the wave's ends).  No packed form.
+__device__ __forceinline__ float lap_rows(float q, float xo, float nmu, float nmd) {
+    asm("v_fmac_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(q) : "v"(xo), "v"(nmu));
+    asm("v_fmac_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(q) : "v"(xo), "v"(nmd));
+    return q;
+}
+__device__ __forceinline__ v2f lap_rows(v2f q, v2f xo, float nmu, float nmd) {
+    return v2f{lap_rows(q.x, xo.x, nmu, nmd), lap_rows(q.y, xo.y, nmu, nmd)};
 }
 
 // Same for a y sweep, with the state (and g) in ROW layout: the second difference (and, when
 // MASKED, the transposed smoothing) runs across lanes (rows h-1, h+1 = lanes l-1, l+1 of the
 // same half).
 template <int N, int J, bool MASKED>
-__device__ __forceinline__ void state_y(const float (&g)[J][N / 2], float (&x)[J][N / 2], float (&acc)[N / 2],
-                                        const float (&kap)[N / 2], const float* rec, int l, int hf, int smooth) {
+__device__ __forceinline__ void state_y(const typename Pack<J>::P (&g)[N / 2], typename Pack<J>::P (&x)[N / 2],
+                                        float (&acc)[N / 2], const float (&kap)[N / 2], const float* rec, int l,
+                                        int hf, int smooth) {
+    using P = typename Pack<J>::P;
     constexpr int M = N / 2;
     float msk[MASKED ? M : 1];
     if constexpr (MASKED) load_half<M>(rec + kB_MaskX + l * kLineStride + hf * kHalfPad, msk);
@@ -584,31 +624,24 @@ __device__ __forceinline__ void state_y(const float (&g)[J][N / 2], float (&x)[J
     const float md = (l < N - 1) ? 1.0f : 0.0f;
     const float nmu = -mu, nmd = -md;
 #pragma unroll
-    for (int j = 0; j < J; ++j) {
-#pragma unroll
-        for (int k = 0; k < M; ++k) {
-            const float xo = x[j][k];
-            float q = kk * xo;
-            // q -= [h>0] x(row h-1) + [h<N-1] x(row h+1): the neighbour rows are the neighbour lanes; the
-            // DPP shift rides on the fmac (src0 = shifted x, 0 shifted in at the wave's ends)
-            asm("v_fmac_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(q) : "v"(xo), "v"(nmu));
-            asm("v_fmac_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(q) : "v"(xo), "v"(nmd));
-            if constexpr (MASKED) {
-                const float gq = g[j][k] * q;
-                float z = gq;
-                if (smooth) {
-                    const float zu = dpp_move<kDppWaveShr1>(gq);
-                    const float zd = dpp_move<kDppWaveShl1>(gq);
-                    z = kz * gq;
-                    z = fmaf(mu, zu, z);
-                    z = fmaf(md, zd, z);
-                }
-                acc[k] = fmaf(msk[k], z, acc[k]);
-            } else {
-                acc[k] = fmaf(g[j][k], q, acc[k]);
+    for (int k = 0; k < M; ++k) {
+        const P xo = x[k];
+        const P q = lap_rows(pk_bc<P>(kk) * xo, xo, nmu, nmd);
+        if constexpr (MASKED) {
+            const P gq = g[k] * q;
+            P z = gq;
+            if (smooth) {
+                const P zu = pk_map(gq, [&](float w) { return dpp_move<kDppWaveShr1>(w); });
+                const P zd = pk_map(gq, [&](float w) { return dpp_move<kDppWaveShl1>(w); });
+                z = pk_bc<P>(kz) * gq;
+                z = pk_fma(pk_bc<P>(mu), zu, z);
+                z = pk_fma(pk_bc<P>(md), zd, z);
             }
-            x[j][k] = fmaf(kap[k], q, xo);
+            acc[k] = fmaf(msk[k], pk_hsum(z), acc[k]);
+        } else {
+            acc[k] = acc_gq(acc[k], g[k], q);
         }
+        x[k] = pk_fma(pk_bc<P>(kap[k]), q, xo);
     }
 }
 
@@ -669,7 +702,8 @@ __global__ __launch_bounds__(kThreads) void adi_bwd_kernel(SweepArgs a) {
         }
     };
 
-    float r[J][M], x[J][M];
+    using P = typename Pack<J>::P;
+    P r[M], x[M];
     int q = g;                                            // chunk of my current item
     bool more = q + a.G < nchunk;
     // The time-weighted sums use summation by parts over the whole processing sequence
@@ -693,16 +727,15 @@ __global__ __launch_bounds__(kThreads) void adi_bwd_kernel(SweepArgs a) {
 #if !(defined(PDE_ABL) && PDE_ABL == 2)
             state_y<N, J, MASKED>(r, x, Ay, ckap, rec, l, hf, a.smooth3);
 #else
-            Ay[0] += r[0][0];
+            Ay[0] += pk_hsum(r[0]);
 #endif
             if (dts != 0.f) {
 #pragma unroll
                 for (int k = 0; k < M; ++k) Ty[k] = fmaf(dts, Ay[k], Ty[k]);
             }
         } else {
-            float xin[J];                                 // partner half's innermost state: issue the
-#pragma unroll
-            for (int j = 0; j < J; ++j) xin[j] = xchg_half(x[j][M - 1], hf);   // exchange now, use it after the solve
+            // partner half's innermost state: issue the exchange now, use it after the solve
+            const P xin = pk_map(x[M - 1], [&](float z) { return xchg_half(z, hf); });
             load_half<M>(crow + kB_E, ce);
             load_half<M>(crow + kB_Inv, cinv);
             solve_adj<M, J>(r, ce, cinv, cjn, hf);
@@ -710,7 +743,7 @@ __global__ __launch_bounds__(kThreads) void adi_bwd_kernel(SweepArgs a) {
 #if !(defined(PDE_ABL) && PDE_ABL == 2)
             state_x<M, J, MASKED>(r, x, Ax, xin, ckap, rec, l, hf, a.smooth3);
 #else
-            Ax[0] += xin[0] + r[0][0];
+            Ax[0] += pk_hsum(xin) + pk_hsum(r[0]);
 #endif
             if (dts != 0.f) {
 #pragma unroll
@@ -723,10 +756,7 @@ __global__ __launch_bounds__(kThreads) void adi_bwd_kernel(SweepArgs a) {
             load_planes<N, J, float>(slot, q, wave, lane, l, hf, a.B, a.C, c, T, x);
             const float sc = tab->ysc[s - 1];             // true state -> rescaled state of sweep s-1
 #pragma unroll
-            for (int j = 0; j < J; ++j) {
-#pragma unroll
-                for (int k = 0; k < M; ++k) x[j][k] *= sc;
-            }
+            for (int k = 0; k < M; ++k) x[k] = x[k] * pk_bc<P>(sc);
         }
     };
     auto chunk_in = [&]() __attribute__((always_inline)) {
@@ -735,10 +765,7 @@ __global__ __launch_bounds__(kThreads) void adi_bwd_kernel(SweepArgs a) {
     };
     auto chunk_out = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < J; ++j) {
-#pragma unroll
-            for (int k = 0; k < M; ++k) r[j][k] *= a.gu_scale;     // undo the (1+eps) carried per sweep
-        }
+        for (int k = 0; k < M; ++k) r[k] = r[k] * pk_bc<P>(a.gu_scale);      // undo the (1+eps) carried per sweep
         store_planes<N, J, IO>(gu, q, wave, lane, l, hf, a.B, a.C, c, T, r);
     };
 
@@ -796,8 +823,20 @@ __global__ __launch_bounds__(kThreads) void adi_bwd_kernel(SweepArgs a) {
                     }
                     ++item;
                 });
+#ifdef PDE_STAMP
+                // every wave of one workgroup, intervals 2 and 3: work done, DMA landed, barrier passed
+                const bool tl_on = (blockIdx.x == 5 && (t == 2 || t == 3) && lane == 0);
+                unsigned long long* tl = reinterpret_cast<unsigned long long*>(a.dbg) + (wave * 2 + (t - 2)) * 3;
+                if (tl_on) tl[0] = stamp();
+#endif
                 dma_wait_all();                           // my DMA pieces (issued a whole step ago) have landed
+#ifdef PDE_STAMP
+                if (tl_on) tl[1] = stamp();
+#endif
                 __syncthreads();                          // ... everyone's have, and everyone is done reading
+#ifdef PDE_STAMP
+                if (tl_on) tl[2] = stamp();
+#endif
             }
         };
         if (lag) run(std::integral_constant<int, 1>{});

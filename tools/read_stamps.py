@@ -24,11 +24,10 @@ d = F_._make_desc(512, 64, 32, 0, [s for st in P.adi_schedule(0.001, 1, 1, 10) f
 total = lib.pde_adi_backward_workspace_bytes(C.byref(d), 0)
 off = total - 512 - 0          # diagnostics scratch sits right before the (empty) checkpoint area
 st = ws[off:off + 48 * 8].cpu().view(torch.int64).tolist()
-# timeline of sweeps 20..15 (processing order) for a lower wave (3) and an upper wave (7) of one workgroup
+# every wave of one workgroup at the end of barrier intervals 2 and 3: work done / DMA landed / barrier passed
 t0 = min(v for v in st if v > 0)
-for w, base in (("wave3 (lower)", 0), ("wave7 (upper, one sweep behind)", 24)):
-    print(w)
-    for i in range(6):
-        e, b, d, s_ = (st[base + 4 * i + k] - t0 for k in range(4))
-        ax = "x" if (20 - i) % 3 != 1 else "y"
-        print(f"  sweep {20 - i} ({ax}): enter {e:6d}  body {b - e:5d}  dma-wait {d - b:4d}  barrier {s_ - d:5d}  -> leaves at {s_:6d}")
+for t in range(2):
+    print("interval", 2 + t)
+    for w in range(8):
+        a_, b_, c_ = (st[(w * 2 + t) * 3 + k] - t0 for k in range(3))
+        print(f"  wave {w}: work done {a_:6d}  dma landed +{b_ - a_:4d}  barrier passed {c_:6d} (waited {c_ - b_:5d})")
