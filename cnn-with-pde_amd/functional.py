@@ -125,7 +125,7 @@ def kappa_max_async(u_like, alpha_base, beta_base, alpha_time_coeff, beta_time_c
     _require_cuda(u_like, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff)
     B, Cc, N, _ = u_like.shape
     p = [_as_chw(t, Cc, N) for t in (alpha_base, beta_base, alpha_time_coeff, beta_time_coeff)]
-    d = _make_desc(B, Cc, N, L.PDE_IO_F32, sweeps, smooth3, clamp_max, eps)
+    d = _make_desc(max(B, 1), Cc, N, L.PDE_IO_F32, sweeps, smooth3, clamp_max, eps)   # independent of the batch
     kdev = torch.empty(len(sweeps), dtype=torch.float32, device=u_like.device)
     with torch.cuda.device(u_like.device):
         L.check(lib.pde_adi_kappa_max(C.byref(d), *[_ptr(t) for t in p], _ptr(kdev), _stream()), "pde_adi_kappa_max")
@@ -202,6 +202,14 @@ class _AdiFn(torch.autograd.Function):
         return (gu, *gp, None, None, None, None, None, None)
 
 
+def _empty_passthrough(u, *params):
+    """Empty batch: nothing to launch.  Like the reference's torch ops, pass the empty tensor through and
+    keep it connected to the parameters (their gradients are zeros, not None)."""
+    _require_cuda(u, *params)
+    tie = sum((p.sum() for p in params if isinstance(p, torch.Tensor)), u.new_zeros(()))
+    return u + 0 * tie.to(u.dtype)
+
+
 def adi_diffuse(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff, sweeps: Sequence[Sweep],
                 smooth3: bool = False, clamp_max: Optional[float] = None, eps: float = 1e-6, checkpoints="auto",
                 kmax_sink: Optional[list] = None):
@@ -215,6 +223,8 @@ def adi_diffuse(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff, swe
     ``kmax_sink``: a list that receives ``(pinned_host_tensor, event)`` with the per-sweep maximum
     coefficient of this call (valid once the event has completed).
     """
+    if u.shape[0] == 0:
+        return _empty_passthrough(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff)
     return _AdiFn.apply(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff, tuple(sweeps),
                         bool(smooth3), clamp_max, float(eps), checkpoints, kmax_sink)
 
@@ -257,6 +267,8 @@ class _MixFn(torch.autograd.Function):
 
 def channel_mix(u, M):
     """out[b,i,p] = sum_j M[i,j] u[b,j,p] — cifar10.py:65-72 and SVHN.py:78-86."""
+    if u.shape[0] == 0:
+        return _empty_passthrough(u, M)
     return _MixFn.apply(u, M)
 
 
@@ -299,6 +311,8 @@ class _Explicit5Fn(torch.autograd.Function):
 
 def explicit5_step(u, alpha_base, channel_scaling, dt=0.01, eps=1e-6, max_coeff=0.15, relax=0.1):
     """One relaxed explicit 5-point step — tiny_imagenet.py:38-49,53-72."""
+    if u.shape[0] == 0:
+        return _empty_passthrough(u, alpha_base, channel_scaling)
     return _Explicit5Fn.apply(u, alpha_base, channel_scaling, float(dt), float(eps), float(max_coeff), float(relax))
 
 
@@ -335,6 +349,8 @@ class _JacobiFn(torch.autograd.Function):
 
 def jacobi_diffuse(u, a_row, b_col, nt: int):
     """emotion_recognition.py:82-97 on (B,H,W): reflect-pad once, ``nt`` Jacobi updates."""
+    if u.shape[0] == 0:
+        return _empty_passthrough(u, a_row, b_col)
     return _JacobiFn.apply(u, a_row, b_col, int(nt))
 
 

@@ -226,6 +226,27 @@ def test_explicit_layers_vs_oracle():
     _compare(pl, lambda a, p: O.emotion_forward(a, p, Nx=40, Ny=40, T=0.004), u, gy, tol=2e-4)
 
 
+def test_empty_batch_passes_through():
+    """B = 0 (the last, empty shard of a ragged split): the reference's torch ops return an empty tensor
+    and zero parameter gradients; so do the layers, without a launch."""
+    import cnn_with_pde_amd as P
+    layers = [(quiet(P.MnistDiffusionLayer, 28), (0, 1, 28, 28)),
+              (quiet(P.SvhnDiffusionLayer, 32, 4, num_steps=2), (0, 4, 32, 32)),
+              (quiet(P.EnhancedDiffusionLayer, 32, 3, num_steps=2), (0, 3, 32, 32)),
+              (quiet(P.ImprovedDiffusionLayer, 32, 5), (0, 5, 32, 32)),
+              (quiet(P.PDELayer, Nx=40, Ny=40), (0, 1, 40, 40))]
+    for layer, shape in layers:
+        layer = layer.cuda()
+        u = torch.zeros(*shape, device="cuda", requires_grad=True)
+        y = layer(u)
+        assert y.shape == u.shape
+        y.sum().backward()
+        assert u.grad is not None and u.grad.shape == u.shape
+        for n, p in layer.named_parameters():
+            if p.grad is not None:
+                assert float(p.grad.abs().max()) == 0.0, (type(layer).__name__, n)
+
+
 # ---- full BASELINE size: properties that do not need the oracle -------------------------------
 @pytest.fixture(scope="module")
 def big():
