@@ -398,7 +398,8 @@ __device__ __forceinline__ int ck_slot(const unsigned long long (&ck)[2], int s)
                   : __builtin_popcountll(ck[0]) + __builtin_popcountll(ck[1] & ((1ull << (s - 64)) - 1ull));
 }
 __device__ __forceinline__ int ck_bit(const unsigned long long (&ck)[2], int s) {
-    return (int)((ck[s >> 6] >> (s & 63)) & 1ull);
+    const unsigned long long w = (s < 64) ? ck[0] : ck[1];      // (a run-time index would put the pair in scratch)
+    return (int)((w >> (s & 63)) & 1ull);
 }
 
 template <int N, int J, typename IO>

@@ -149,7 +149,7 @@ template <> struct Io4<bf16s> {
 constexpr int kMixTG = 2;      // output-channel tiles (of 32) accumulated per pass over the input
 
 template <typename IO>
-__global__ __launch_bounds__(256) void mix_apply_mfma_kernel(const IO* __restrict__ u, const float* __restrict__ M,
+__global__ __launch_bounds__(256, 2) void mix_apply_mfma_kernel(const IO* __restrict__ u, const float* __restrict__ M,
                                                              IO* __restrict__ out, int B, int C, int HW, int trans) {
     extern __shared__ float wfrag[];                    // [C/32 tiles][C/2 k-steps][64 lanes]: A fragments of W
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
