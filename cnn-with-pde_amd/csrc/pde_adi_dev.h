@@ -192,8 +192,16 @@ __device__ __forceinline__ void stage_store(float* dst, int tid, const Staged& s
 template <typename IO> struct IoTraits;
 template <> struct IoTraits<float> {
     static constexpr int kVec = 4;                      // elements per 16-byte access
-    __device__ static __forceinline__ float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-    __device__ static __forceinline__ void store4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+    // planes are touched exactly once per launch: non-temporal, so that they stream past the L2 lines
+    // that hold the coefficient records (re-read by every chunk of every workgroup of the channel)
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    __device__ static __forceinline__ float4 load4(const float* p) {
+        const f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+    __device__ static __forceinline__ void store4(float* p, float4 v) {
+        __builtin_nontemporal_store(f4{v.x, v.y, v.z, v.w}, reinterpret_cast<f4*>(p));
+    }
 };
 struct bf16_t { unsigned short v; };
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned int)h << 16); }
@@ -205,13 +213,14 @@ __device__ __forceinline__ unsigned short f32_to_bf16(float f) {      // round t
 }
 template <> struct IoTraits<bf16_t> {
     __device__ static __forceinline__ float4 load4(const bf16_t* p) {
-        const ushort4 q = *reinterpret_cast<const ushort4*>(p);
+        typedef unsigned short u4 __attribute__((ext_vector_type(4)));
+        const u4 q = __builtin_nontemporal_load(reinterpret_cast<const u4*>(p));
         return make_float4(bf16_to_f32(q.x), bf16_to_f32(q.y), bf16_to_f32(q.z), bf16_to_f32(q.w));
     }
     __device__ static __forceinline__ void store4(bf16_t* p, float4 v) {
-        ushort4 q;
-        q.x = f32_to_bf16(v.x); q.y = f32_to_bf16(v.y); q.z = f32_to_bf16(v.z); q.w = f32_to_bf16(v.w);
-        *reinterpret_cast<ushort4*>(p) = q;
+        typedef unsigned short u4 __attribute__((ext_vector_type(4)));
+        const u4 q = {f32_to_bf16(v.x), f32_to_bf16(v.y), f32_to_bf16(v.z), f32_to_bf16(v.w)};
+        __builtin_nontemporal_store(q, reinterpret_cast<u4*>(p));
     }
 };
 
