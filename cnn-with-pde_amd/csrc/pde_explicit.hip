@@ -32,8 +32,16 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
 template <typename IO> struct V4;
 template <> struct V4<float> {
     __device__ static __forceinline__ float4 ld(const float* p) { return *reinterpret_cast<const float4*>(p); }
-    __device__ static __forceinline__ void st(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+    __device__ static __forceinline__ void st(float* p, float4 v) {       // written once, never re-read here
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(f4{v.x, v.y, v.z, v.w}, reinterpret_cast<f4*>(p));
+    }
     __device__ static __forceinline__ float ld1(const float* p) { return *p; }
+    __device__ static __forceinline__ float4 ld_once(const float* p) {    // no neighbour re-reads this one
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
 };
 template <> struct V4<bf16e> {
     __device__ static __forceinline__ float4 ld(const bf16e* p) {
@@ -45,6 +53,7 @@ template <> struct V4<bf16e> {
         *reinterpret_cast<ushort4*>(p) = q;
     }
     __device__ static __forceinline__ float ld1(const bf16e* p) { return bf2f(p->v); }
+    __device__ static __forceinline__ float4 ld_once(const bf16e* p) { return ld(p); }
 };
 
 // 5-point Laplacian with zero ghost cells of 4 consecutive columns (h, w0..w0+3) of one plane
@@ -117,7 +126,7 @@ __global__ __launch_bounds__(256) void explicit5_bwd_kernel(const IO* __restrict
     for (int f = threadIdx.x; f < H * W4; f += 256) {
         const int h = f / W4, w0 = 4 * (f % W4);
         const float4 cg = V4<IO>::ld(gp + (size_t)h * W + w0);
-        const float4 cu = V4<IO>::ld(up + (size_t)h * W + w0);
+        const float4 cu = V4<IO>::ld_once(up + (size_t)h * W + w0);
         const float4 lg = lap0_4<IO>(gp, H, W, h, w0, cg);
         float4 o;
         o.x = (1.f - relax) * cg.x + relax * s * (cg.x + a * lg.x);
