@@ -10,6 +10,8 @@
 // tiles, split over K across workgroups, partial tiles reduced in a fixed order.
 #include "pde_common.h"
 
+#include <cstdlib>
+
 namespace pde {
 namespace {
 
@@ -105,16 +107,27 @@ __global__ __launch_bounds__(256) void mix_gm_kernel(const IO* __restrict__ u, c
 
 __global__ __launch_bounds__(256) void mix_gm_reduce_kernel(const float* __restrict__ part, float* __restrict__ gM,
                                                             int CC, int nsplit) {
-    // 64 outputs per workgroup; thread (q, e) adds splits q, q+4, ... of output e, the four partial
-    // sums are combined in a fixed order (bitwise reproducible)
-    __shared__ float sh[4][64];
-    const int e = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    // 32 outputs per workgroup; thread (q, e) adds splits q, q+8, ... of output e (16 loads in flight),
+    // the eight partial sums are combined in a fixed order (bitwise reproducible)
+    __shared__ float sh[8][32];
+    const int el = threadIdx.x & 31, q = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + el;
     float s = 0.f;
-    if (e < CC)
-        for (int k = q; k < nsplit; k += 4) s += part[(size_t)k * CC + e];
-    sh[q][threadIdx.x & 63] = s;
+    if (e < CC) {
+        int k = q;
+        for (; k + 8 * 15 < nsplit; k += 8 * 16) {
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = part[(size_t)(k + 8 * i) * CC + e];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s += v[i];
+        }
+        for (; k < nsplit; k += 8) s += part[(size_t)k * CC + e];
+    }
+    sh[q][el] = s;
     __syncthreads();
-    if (q == 0 && e < CC) gM[e] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    if (q == 0 && e < CC)
+        gM[e] = ((sh[0][el] + sh[1][el]) + (sh[2][el] + sh[3][el])) + ((sh[4][el] + sh[5][el]) + (sh[6][el] + sh[7][el]));
 }
 
 // ---- fp32 MFMA path (C a multiple of 32) -------------------------------------------------
@@ -292,6 +305,88 @@ __global__ __launch_bounds__(256) void mix_gm_mfma_kernel(const IO* __restrict__
     }
 }
 
+// Backward of the mixing in ONE pass for C = 64 (the cifar10 width): a workgroup stages a
+// [64 channels][64 pixels] tile of g and of u in LDS (as mix_gm_mfma_kernel does) and uses it twice,
+//   gu tile  = M^T g     (A = M^T fragments from LDS, B = g rows;  wave w: channel tile w/2, pixel half w%2)
+//   gM part += g u^T     (A = g, B = u, contraction over the 64 pixels;  wave w: output tile w)
+// so g is read once instead of twice and the two products share the staging: 12 B/element
+// (read g, u; write gu) instead of 8 + 8.  Partial gM matrices are reduced by mix_gm_reduce_kernel.
+template <typename IO>
+__global__ __launch_bounds__(256) void mix_bwd_fused_kernel(const IO* __restrict__ u, const IO* __restrict__ g,
+                                                            const float* __restrict__ M, IO* __restrict__ gu,
+                                                            float* __restrict__ part, int B, int HW, int nsplit) {
+    constexpr int C = 64, KS = C / 2;
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // wfrag [2][KS][64] | sg [C][kGmLd] | su [C][kGmLd]
+    float* wfrag = sm;
+    float* sg = sm + C * C;
+    float* su = sg + C * kGmLd;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kh = lane >> 5, jj = lane & 31;
+    for (int e = tid; e < C * C; e += 256) {                       // A fragments of M^T: A[i][k] = M[k][i]
+        const int ln = e & 63, ks = (e >> 6) % KS, it = (e >> 6) / KS;
+        const int i = 32 * it + (ln & 31), k = 2 * ks + (ln >> 5);
+        wfrag[e] = M[k * C + i];
+    }
+    f32x16 acc_m;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_m[r] = 0.f;
+    const int mt_i = wave >> 1, mt_j = wave & 1;                   // my gM tile; also my gu tile (channel tile, pixel half)
+    const int per_sample = (HW + kGmKP - 1) / kGmKP;
+    const long total = (long)B * per_sample;
+    for (long ch = blockIdx.x; ch < total; ch += nsplit) {
+        const int b = (int)(ch / per_sample);
+        const int p0 = (int)(ch % per_sample) * kGmKP;
+        __syncthreads();                               // previous chunk fully consumed (and wfrag written)
+        for (int e = tid; e < C * (kGmKP / 4); e += 256) {
+            const int c = e / (kGmKP / 4), c4 = e % (kGmKP / 4);
+            const int p = p0 + 4 * c4;
+            const bool pv = p < HW;
+            const size_t off = ((size_t)b * C + c) * HW + p;
+            const float4 gv = pv ? Io4<IO>::ld(g + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 uv = pv ? Io4<IO>::ld(u + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float* dg = sg + c * kGmLd + 4 * c4;
+            float* du = su + c * kGmLd + 4 * c4;
+            *reinterpret_cast<float2*>(dg) = make_float2(gv.x, gv.y); *reinterpret_cast<float2*>(dg + 2) = make_float2(gv.z, gv.w);
+            *reinterpret_cast<float2*>(du) = make_float2(uv.x, uv.y); *reinterpret_cast<float2*>(du + 2) = make_float2(uv.z, uv.w);
+        }
+        __syncthreads();
+        f32x16 acc_u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_u[r] = 0.f;
+#pragma unroll 4
+        for (int ks = 0; ks < KS; ++ks) {
+            // gM: contraction index = pixel pair ks of the tile
+            const float am = sg[(32 * mt_i + jj) * kGmLd + 2 * ks + kh];
+            const float bm = su[(32 * mt_j + jj) * kGmLd + 2 * ks + kh];
+            acc_m = __builtin_amdgcn_mfma_f32_32x32x2f32(am, bm, acc_m, 0, 0, 0);
+            // gu: contraction index = channel pair ks
+            const float au = wfrag[(mt_i * KS + ks) * 64 + lane];
+            const float bu = sg[(2 * ks + kh) * kGmLd + 32 * mt_j + jj];
+            acc_u = __builtin_amdgcn_mfma_f32_32x32x2f32(au, bu, acc_u, 0, 0, 0);
+        }
+        const int px = p0 + 32 * mt_j + jj;
+        if (px < HW) {
+            IO* ob = gu + (size_t)b * C * HW + px;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int chn = 32 * mt_i + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                Io<IO>::st(ob + (size_t)chn * HW, acc_u[r]);
+            }
+        }
+    }
+    float* dst = part + (size_t)blockIdx.x * C * C;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = 32 * mt_i + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        dst[i * C + 32 * mt_j + jj] = acc_m[r];
+    }
+}
+bool mfma_fused_ok(int C, int HW) { return C == 64 && (HW % 4) == 0; }
+int fused_splits(int B, int HW) {
+    const long chunks = (long)B * ((HW + kGmKP - 1) / kGmKP);
+    return (int)(chunks < 768 ? chunks : 768);       // 3 workgroups per CU (50 KB of LDS each)
+}
+
 bool mfma_apply_ok(int C, int HW) { return (C % 32) == 0 && C <= 128 && (HW % 4) == 0; }   // W fragments: C*C*4 B of LDS
 bool mfma_gm_ok(int C, int HW) { return (C == 64 || C == 128) && (HW % 4) == 0; }
 int gm_mfma_splits(int B, int HW) {
@@ -349,7 +444,7 @@ int pde_channel_mix_forward(int32_t B, int32_t C, int32_t HW, int32_t io_dtype, 
 
 size_t pde_channel_mix_backward_workspace_bytes(int32_t B, int32_t C, int32_t HW) {
     if (B <= 0 || C <= 0 || HW <= 0) return 0;
-    const int n = mfma_gm_ok(C, HW) ? gm_mfma_splits(B, HW) : gm_splits(B, C, HW);
+    const int n = mfma_fused_ok(C, HW) ? fused_splits(B, HW) : mfma_gm_ok(C, HW) ? gm_mfma_splits(B, HW) : gm_splits(B, C, HW);
     return (size_t)n * C * C * sizeof(float);
 }
 
@@ -363,6 +458,21 @@ int pde_channel_mix_backward(int32_t B, int32_t C, int32_t HW, int32_t io_dtype,
     dim3 grid((HW + 255) / 256, B);
     const int tiles = (C + kT - 1) / kT;
     float* part = static_cast<float*>(workspace);
+    if (mfma_fused_ok(C, HW) && getenv("PDE_MIX_UNFUSED") == nullptr) {
+        const int nsplit = fused_splits(B, HW);
+        const size_t lds = (size_t)(C * C + 2 * C * kGmLd) * sizeof(float);
+        if (io_dtype == PDE_IO_F32) {
+            static bool cfg = false;
+            if (!cfg) { (void)hipFuncSetAttribute((const void*)mix_bwd_fused_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); cfg = true; }
+            hipLaunchKernelGGL((mix_bwd_fused_kernel<float>), dim3(nsplit), dim3(256), lds, st, (const float*)u, (const float*)gout, M, (float*)gu, part, B, HW, nsplit);
+        } else {
+            static bool cfg = false;
+            if (!cfg) { (void)hipFuncSetAttribute((const void*)mix_bwd_fused_kernel<bf16s>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); cfg = true; }
+            hipLaunchKernelGGL((mix_bwd_fused_kernel<bf16s>), dim3(nsplit), dim3(256), lds, st, (const bf16s*)u, (const bf16s*)gout, M, (bf16s*)gu, part, B, HW, nsplit);
+        }
+        hipLaunchKernelGGL(mix_gm_reduce_kernel, dim3((C * C + 31) / 32), dim3(256), 0, st, part, gM, C * C, nsplit);
+        return check_launch();
+    }
     // gu = M^T gout
     if (mfma_apply_ok(C, HW)) {
         const int rc = launch_apply_mfma(B, C, HW, io_dtype, gout, M, gu, 1, st);
@@ -395,7 +505,7 @@ int pde_channel_mix_backward(int32_t B, int32_t C, int32_t HW, int32_t io_dtype,
             hipLaunchKernelGGL((mix_gm_kernel<bf16s>), dim3(tiles * tiles, nsplit), dim3(256), 0, st, (const bf16s*)u,
                                (const bf16s*)gout, part, B, C, HW, nsplit);
     }
-    hipLaunchKernelGGL(mix_gm_reduce_kernel, dim3((C * C + 63) / 64), dim3(256), 0, st, part, gM, C * C, nsplit);
+    hipLaunchKernelGGL(mix_gm_reduce_kernel, dim3((C * C + 31) / 32), dim3(256), 0, st, part, gM, C * C, nsplit);
     return check_launch();
 }
 
