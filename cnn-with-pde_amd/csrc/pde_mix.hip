@@ -305,39 +305,44 @@ __global__ __launch_bounds__(256) void mix_gm_mfma_kernel(const IO* __restrict__
     }
 }
 
-// Backward of the mixing in ONE pass for C = 64 (the cifar10 width): a workgroup stages a
-// [64 channels][64 pixels] tile of g and of u in LDS (as mix_gm_mfma_kernel does) and uses it twice,
-//   gu tile  = M^T g     (A = M^T fragments from LDS, B = g rows;  wave w: channel tile w/2, pixel half w%2)
-//   gM part += g u^T     (A = g, B = u, contraction over the 64 pixels;  wave w: output tile w)
+// Backward of the mixing in ONE pass (C = 64: the cifar10 width, 4 waves; C = 128: the SVHN width,
+// 8 waves): a workgroup stages a [C channels][64 pixels] tile of g and of u in LDS (as
+// mix_gm_mfma_kernel does) and uses it twice,
+//   gu tile  = M^T g     (A = M^T fragments from LDS, B = g rows;  tile = (channel tile, pixel half))
+//   gM part += g u^T     (A = g, B = u, contraction over the 64 pixels;  tile = (i tile, j tile))
 // so g is read once instead of twice and the two products share the staging: 12 B/element
 // (read g, u; write gu) instead of 8 + 8.  Partial gM matrices are reduced by mix_gm_reduce_kernel.
-template <typename IO>
-__global__ __launch_bounds__(256) void mix_bwd_fused_kernel(const IO* __restrict__ u, const IO* __restrict__ g,
-                                                            const float* __restrict__ M, IO* __restrict__ gu,
-                                                            float* __restrict__ part, int B, int HW, int nsplit) {
-    constexpr int C = 64, KS = C / 2;
-    extern __shared__ __attribute__((aligned(16))) float sm[];   // wfrag [2][KS][64] | sg [C][kGmLd] | su [C][kGmLd]
+template <typename IO, int C, int W>
+__global__ __launch_bounds__(64 * W) void mix_bwd_fused_kernel(const IO* __restrict__ u, const IO* __restrict__ g,
+                                                               const float* __restrict__ M, IO* __restrict__ gu,
+                                                               float* __restrict__ part, int B, int HW, int nsplit) {
+    constexpr int KS = C / 2, T = C / 32, NT = 64 * W;
+    constexpr int NTM = T * T / W;                       // gM tiles per wave
+    constexpr int NTU = 2 * T / W;                       // gu tiles per wave
+    static_assert(NTM >= 1 && NTU >= 1 && T * T % W == 0 && 2 * T % W == 0, "tile split");
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // wfrag [T][KS][64] | sg [C][kGmLd] | su [C][kGmLd]
     float* wfrag = sm;
     float* sg = sm + C * C;
     float* su = sg + C * kGmLd;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kh = lane >> 5, jj = lane & 31;
-    for (int e = tid; e < C * C; e += 256) {                       // A fragments of M^T: A[i][k] = M[k][i]
+    for (int e = tid; e < C * C; e += NT) {                        // A fragments of M^T: A[i][k] = M[k][i]
         const int ln = e & 63, ks = (e >> 6) % KS, it = (e >> 6) / KS;
         const int i = 32 * it + (ln & 31), k = 2 * ks + (ln >> 5);
         wfrag[e] = M[k * C + i];
     }
-    f32x16 acc_m;
+    f32x16 acc_m[NTM];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc_m[r] = 0.f;
-    const int mt_i = wave >> 1, mt_j = wave & 1;                   // my gM tile; also my gu tile (channel tile, pixel half)
+    for (int t = 0; t < NTM; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_m[t][r] = 0.f;
     const int per_sample = (HW + kGmKP - 1) / kGmKP;
     const long total = (long)B * per_sample;
     for (long ch = blockIdx.x; ch < total; ch += nsplit) {
         const int b = (int)(ch / per_sample);
         const int p0 = (int)(ch % per_sample) * kGmKP;
         __syncthreads();                               // previous chunk fully consumed (and wfrag written)
-        for (int e = tid; e < C * (kGmKP / 4); e += 256) {
+        for (int e = tid; e < C * (kGmKP / 4); e += NT) {
             const int c = e / (kGmKP / 4), c4 = e % (kGmKP / 4);
             const int p = p0 + 4 * c4;
             const bool pv = p < HW;
@@ -350,41 +355,71 @@ __global__ __launch_bounds__(256) void mix_bwd_fused_kernel(const IO* __restrict
             *reinterpret_cast<float2*>(du) = make_float2(uv.x, uv.y); *reinterpret_cast<float2*>(du + 2) = make_float2(uv.z, uv.w);
         }
         __syncthreads();
-        f32x16 acc_u;
+        // gM: contraction index = pixel pair ks of the tile
+#pragma unroll 4
+        for (int ks = 0; ks < kGmKP / 2; ++ks) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc_u[r] = 0.f;
+            for (int t = 0; t < NTM; ++t) {
+                const int tile = wave + W * t, it = tile / T, jt = tile % T;
+                const float am = sg[(32 * it + jj) * kGmLd + 2 * ks + kh];
+                const float bm = su[(32 * jt + jj) * kGmLd + 2 * ks + kh];
+                acc_m[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(am, bm, acc_m[t], 0, 0, 0);
+            }
+        }
+        // gu: contraction index = channel pair ks
+        f32x16 acc_u[NTU];
+#pragma unroll
+        for (int t = 0; t < NTU; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_u[t][r] = 0.f;
 #pragma unroll 4
         for (int ks = 0; ks < KS; ++ks) {
-            // gM: contraction index = pixel pair ks of the tile
-            const float am = sg[(32 * mt_i + jj) * kGmLd + 2 * ks + kh];
-            const float bm = su[(32 * mt_j + jj) * kGmLd + 2 * ks + kh];
-            acc_m = __builtin_amdgcn_mfma_f32_32x32x2f32(am, bm, acc_m, 0, 0, 0);
-            // gu: contraction index = channel pair ks
-            const float au = wfrag[(mt_i * KS + ks) * 64 + lane];
-            const float bu = sg[(2 * ks + kh) * kGmLd + 32 * mt_j + jj];
-            acc_u = __builtin_amdgcn_mfma_f32_32x32x2f32(au, bu, acc_u, 0, 0, 0);
-        }
-        const int px = p0 + 32 * mt_j + jj;
-        if (px < HW) {
-            IO* ob = gu + (size_t)b * C * HW + px;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int chn = 32 * mt_i + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                Io<IO>::st(ob + (size_t)chn * HW, acc_u[r]);
+            for (int t = 0; t < NTU; ++t) {
+                const int tile = wave + W * t, ot = tile >> 1, pg = tile & 1;
+                const float au = wfrag[(ot * KS + ks) * 64 + lane];
+                const float bu = sg[(2 * ks + kh) * kGmLd + 32 * pg + jj];
+                acc_u[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(au, bu, acc_u[t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NTU; ++t) {
+            const int tile = wave + W * t, ot = tile >> 1, pg = tile & 1;
+            const int px = p0 + 32 * pg + jj;
+            if (px < HW) {
+                IO* ob = gu + (size_t)b * C * HW + px;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int chn = 32 * ot + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    Io<IO>::st(ob + (size_t)chn * HW, acc_u[t][r]);
+                }
             }
         }
     }
     float* dst = part + (size_t)blockIdx.x * C * C;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int i = 32 * mt_i + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        dst[i * C + 32 * mt_j + jj] = acc_m[r];
+    for (int t = 0; t < NTM; ++t) {
+        const int tile = wave + W * t, it = tile / T, jt = tile % T;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = 32 * it + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            dst[i * C + 32 * jt + jj] = acc_m[t][r];
+        }
     }
 }
-bool mfma_fused_ok(int C, int HW) { return C == 64 && (HW % 4) == 0; }
-int fused_splits(int B, int HW) {
+bool mfma_fused_ok(int C, int HW) { return (C == 64 || C == 128) && (HW % 4) == 0; }
+int fused_splits(int B, int C, int HW) {
     const long chunks = (long)B * ((HW + kGmKP - 1) / kGmKP);
-    return (int)(chunks < 768 ? chunks : 768);       // 3 workgroups per CU (50 KB of LDS each)
+    const long want = C == 64 ? 768 : 256;           // workgroups resident at once: 3 per CU (50 KB of LDS) / 1 (130 KB)
+    return (int)(chunks < want ? chunks : want);
+}
+template <typename IO, int C, int W>
+void launch_fused(const void* u, const void* g, const float* M, void* gu, float* part, int B, int HW, int nsplit,
+                  hipStream_t st) {
+    const size_t lds = (size_t)(C * C + 2 * C * kGmLd) * sizeof(float);
+    static bool cfg = false;
+    if (!cfg) { (void)hipFuncSetAttribute((const void*)mix_bwd_fused_kernel<IO, C, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); cfg = true; }
+    hipLaunchKernelGGL((mix_bwd_fused_kernel<IO, C, W>), dim3(nsplit), dim3(64 * W), lds, st, (const IO*)u, (const IO*)g, M, (IO*)gu, part, B, HW, nsplit);
 }
 
 bool mfma_apply_ok(int C, int HW) { return (C % 32) == 0 && C <= 128 && (HW % 4) == 0; }   // W fragments: C*C*4 B of LDS
@@ -444,7 +479,7 @@ int pde_channel_mix_forward(int32_t B, int32_t C, int32_t HW, int32_t io_dtype, 
 
 size_t pde_channel_mix_backward_workspace_bytes(int32_t B, int32_t C, int32_t HW) {
     if (B <= 0 || C <= 0 || HW <= 0) return 0;
-    const int n = mfma_fused_ok(C, HW) ? fused_splits(B, HW) : mfma_gm_ok(C, HW) ? gm_mfma_splits(B, HW) : gm_splits(B, C, HW);
+    const int n = mfma_fused_ok(C, HW) ? fused_splits(B, C, HW) : mfma_gm_ok(C, HW) ? gm_mfma_splits(B, HW) : gm_splits(B, C, HW);
     return (size_t)n * C * C * sizeof(float);
 }
 
@@ -459,16 +494,13 @@ int pde_channel_mix_backward(int32_t B, int32_t C, int32_t HW, int32_t io_dtype,
     const int tiles = (C + kT - 1) / kT;
     float* part = static_cast<float*>(workspace);
     if (mfma_fused_ok(C, HW) && getenv("PDE_MIX_UNFUSED") == nullptr) {
-        const int nsplit = fused_splits(B, HW);
-        const size_t lds = (size_t)(C * C + 2 * C * kGmLd) * sizeof(float);
+        const int nsplit = fused_splits(B, C, HW);
         if (io_dtype == PDE_IO_F32) {
-            static bool cfg = false;
-            if (!cfg) { (void)hipFuncSetAttribute((const void*)mix_bwd_fused_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); cfg = true; }
-            hipLaunchKernelGGL((mix_bwd_fused_kernel<float>), dim3(nsplit), dim3(256), lds, st, (const float*)u, (const float*)gout, M, (float*)gu, part, B, HW, nsplit);
+            if (C == 64) launch_fused<float, 64, 4>(u, gout, M, gu, part, B, HW, nsplit, st);
+            else launch_fused<float, 128, 8>(u, gout, M, gu, part, B, HW, nsplit, st);
         } else {
-            static bool cfg = false;
-            if (!cfg) { (void)hipFuncSetAttribute((const void*)mix_bwd_fused_kernel<bf16s>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); cfg = true; }
-            hipLaunchKernelGGL((mix_bwd_fused_kernel<bf16s>), dim3(nsplit), dim3(256), lds, st, (const bf16s*)u, (const bf16s*)gout, M, (bf16s*)gu, part, B, HW, nsplit);
+            if (C == 64) launch_fused<bf16s, 64, 4>(u, gout, M, gu, part, B, HW, nsplit, st);
+            else launch_fused<bf16s, 128, 8>(u, gout, M, gu, part, B, HW, nsplit, st);
         }
         hipLaunchKernelGGL(mix_gm_reduce_kernel, dim3((C * C + 31) / 32), dim3(256), 0, st, part, gM, C * C, nsplit);
         return check_launch();
