@@ -312,24 +312,30 @@ __global__ __launch_bounds__(256) void mix_gm_mfma_kernel(const IO* __restrict__
 //   gM part += g u^T     (A = g, B = u, contraction over the 64 pixels;  tile = (i tile, j tile))
 // so g is read once instead of twice and the two products share the staging: 12 B/element
 // (read g, u; write gu) instead of 8 + 8.  Partial gM matrices are reduced by mix_gm_reduce_kernel.
-template <typename IO, int C, int W>
+// WLDS: the M^T fragment table sits in LDS (C = 64: 16 KB); for C = 128 it would take 64 KB and leave
+// room for one workgroup per CU only, so there the fragments are read from the (L2-resident) table
+// `Mfrag` that mix_frag_kernel lays out once per call, and two workgroups overlap staging with MFMAs.
+template <typename IO, int C, int W, bool WLDS>
 __global__ __launch_bounds__(64 * W) void mix_bwd_fused_kernel(const IO* __restrict__ u, const IO* __restrict__ g,
-                                                               const float* __restrict__ M, IO* __restrict__ gu,
-                                                               float* __restrict__ part, int B, int HW, int nsplit) {
+                                                               const float* __restrict__ M, const float* __restrict__ Mfrag,
+                                                               IO* __restrict__ gu, float* __restrict__ part, int B, int HW,
+                                                               int nsplit) {
     constexpr int KS = C / 2, T = C / 32, NT = 64 * W;
     constexpr int NTM = T * T / W;                       // gM tiles per wave
     constexpr int NTU = 2 * T / W;                       // gu tiles per wave
     static_assert(NTM >= 1 && NTU >= 1 && T * T % W == 0 && 2 * T % W == 0, "tile split");
     extern __shared__ __attribute__((aligned(16))) float sm[];   // wfrag [T][KS][64] | sg [C][kGmLd] | su [C][kGmLd]
     float* wfrag = sm;
-    float* sg = sm + C * C;
+    float* sg = sm + (WLDS ? C * C : 0);
     float* su = sg + C * kGmLd;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kh = lane >> 5, jj = lane & 31;
-    for (int e = tid; e < C * C; e += NT) {                        // A fragments of M^T: A[i][k] = M[k][i]
-        const int ln = e & 63, ks = (e >> 6) % KS, it = (e >> 6) / KS;
-        const int i = 32 * it + (ln & 31), k = 2 * ks + (ln >> 5);
-        wfrag[e] = M[k * C + i];
+    if constexpr (WLDS) {
+        for (int e = tid; e < C * C; e += NT) {                    // A fragments of M^T: A[i][k] = M[k][i]
+            const int ln = e & 63, ks = (e >> 6) % KS, it = (e >> 6) / KS;
+            const int i = 32 * it + (ln & 31), k = 2 * ks + (ln >> 5);
+            wfrag[e] = M[k * C + i];
+        }
     }
     f32x16 acc_m[NTM];
 #pragma unroll
@@ -377,7 +383,7 @@ __global__ __launch_bounds__(64 * W) void mix_bwd_fused_kernel(const IO* __restr
 #pragma unroll
             for (int t = 0; t < NTU; ++t) {
                 const int tile = wave + W * t, ot = tile >> 1, pg = tile & 1;
-                const float au = wfrag[(ot * KS + ks) * 64 + lane];
+                const float au = WLDS ? wfrag[(ot * KS + ks) * 64 + lane] : Mfrag[(ot * KS + ks) * 64 + lane];
                 const float bu = sg[(2 * ks + kh) * kGmLd + 32 * pg + jj];
                 acc_u[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(au, bu, acc_u[t], 0, 0, 0);
             }
@@ -407,19 +413,30 @@ __global__ __launch_bounds__(64 * W) void mix_bwd_fused_kernel(const IO* __restr
         }
     }
 }
+// fragment table of M^T in the order the MFMA A operand wants it: [C/32 tiles][C/2 k-steps][64 lanes]
+__global__ __launch_bounds__(256) void mix_frag_kernel(const float* __restrict__ M, float* __restrict__ frag, int C) {
+    const int KS = C / 2;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= C * C) return;
+    const int ln = e & 63, ks = (e >> 6) % KS, it = (e >> 6) / KS;
+    const int i = 32 * it + (ln & 31), k = 2 * ks + (ln >> 5);
+    frag[e] = M[k * C + i];
+}
 bool mfma_fused_ok(int C, int HW) { return (C == 64 || C == 128) && (HW % 4) == 0; }
 int fused_splits(int B, int C, int HW) {
     const long chunks = (long)B * ((HW + kGmKP - 1) / kGmKP);
-    const long want = C == 64 ? 768 : 256;           // workgroups resident at once: 3 per CU (50 KB of LDS) / 1 (130 KB)
+    const long want = C == 64 ? 768 : 512;           // workgroups resident at once: 3 per CU (50 KB of LDS) / 2 (68 KB)
     return (int)(chunks < want ? chunks : want);
 }
-template <typename IO, int C, int W>
+template <typename IO, int C, int W, bool WLDS>
 void launch_fused(const void* u, const void* g, const float* M, void* gu, float* part, int B, int HW, int nsplit,
                   hipStream_t st) {
-    const size_t lds = (size_t)(C * C + 2 * C * kGmLd) * sizeof(float);
+    const size_t lds = (size_t)((WLDS ? C * C : 0) + 2 * C * kGmLd) * sizeof(float);
+    float* frag = part + (size_t)nsplit * C * C;     // behind the partial matrices (workspace sized for it)
+    if (!WLDS) hipLaunchKernelGGL(mix_frag_kernel, dim3((C * C + 255) / 256), dim3(256), 0, st, M, frag, C);
     static bool cfg = false;
-    if (!cfg) { (void)hipFuncSetAttribute((const void*)mix_bwd_fused_kernel<IO, C, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); cfg = true; }
-    hipLaunchKernelGGL((mix_bwd_fused_kernel<IO, C, W>), dim3(nsplit), dim3(64 * W), lds, st, (const IO*)u, (const IO*)g, M, (IO*)gu, part, B, HW, nsplit);
+    if (!cfg) { (void)hipFuncSetAttribute((const void*)mix_bwd_fused_kernel<IO, C, W, WLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); cfg = true; }
+    hipLaunchKernelGGL((mix_bwd_fused_kernel<IO, C, W, WLDS>), dim3(nsplit), dim3(64 * W), lds, st, (const IO*)u, (const IO*)g, M, frag, (IO*)gu, part, B, HW, nsplit);
 }
 
 bool mfma_apply_ok(int C, int HW) { return (C % 32) == 0 && C <= 128 && (HW % 4) == 0; }   // W fragments: C*C*4 B of LDS
@@ -480,7 +497,7 @@ int pde_channel_mix_forward(int32_t B, int32_t C, int32_t HW, int32_t io_dtype, 
 size_t pde_channel_mix_backward_workspace_bytes(int32_t B, int32_t C, int32_t HW) {
     if (B <= 0 || C <= 0 || HW <= 0) return 0;
     const int n = mfma_fused_ok(C, HW) ? fused_splits(B, C, HW) : mfma_gm_ok(C, HW) ? gm_mfma_splits(B, HW) : gm_splits(B, C, HW);
-    return (size_t)n * C * C * sizeof(float);
+    return (size_t)(n + 1) * C * C * sizeof(float);      // partial matrices + one fragment table
 }
 
 int pde_channel_mix_backward(int32_t B, int32_t C, int32_t HW, int32_t io_dtype, const void* u, const void* gout,
@@ -496,11 +513,11 @@ int pde_channel_mix_backward(int32_t B, int32_t C, int32_t HW, int32_t io_dtype,
     if (mfma_fused_ok(C, HW) && getenv("PDE_MIX_UNFUSED") == nullptr) {
         const int nsplit = fused_splits(B, C, HW);
         if (io_dtype == PDE_IO_F32) {
-            if (C == 64) launch_fused<float, 64, 4>(u, gout, M, gu, part, B, HW, nsplit, st);
-            else launch_fused<float, 128, 8>(u, gout, M, gu, part, B, HW, nsplit, st);
+            if (C == 64) launch_fused<float, 64, 4, true>(u, gout, M, gu, part, B, HW, nsplit, st);
+            else launch_fused<float, 128, 8, false>(u, gout, M, gu, part, B, HW, nsplit, st);
         } else {
-            if (C == 64) launch_fused<bf16s, 64, 4>(u, gout, M, gu, part, B, HW, nsplit, st);
-            else launch_fused<bf16s, 128, 8>(u, gout, M, gu, part, B, HW, nsplit, st);
+            if (C == 64) launch_fused<bf16s, 64, 4, true>(u, gout, M, gu, part, B, HW, nsplit, st);
+            else launch_fused<bf16s, 128, 8, false>(u, gout, M, gu, part, B, HW, nsplit, st);
         }
         hipLaunchKernelGGL(mix_gm_reduce_kernel, dim3((C * C + 31) / 32), dim3(256), 0, st, part, gM, C * C, nsplit);
         return check_launch();
