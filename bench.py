@@ -179,11 +179,13 @@ def main():
 
     out = None
     if rank == 0:
-        pmc = None
+        pmc, valu = None, None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.isfile(pmc_path):
+        if os.path.isfile(pmc_path) and (B, C, N, steps) == (512, 64, 32, 10):     # counters were taken on this workload
             with open(pmc_path) as f:
-                pmc = json.load(f).get("adi_bwd_kernel_bytes_per_launch")
+                pj = json.load(f)
+            pmc = pj.get("adi_bwd_kernel_bytes_per_launch")
+            valu = pj.get("sq_insts_valu_per_launch")
         ach = elems * BYTES_PER_ELEM["bwd"] / (bwd_ms * 1e-3) / 1e9
         out = {
             "metric": "PDE-layer fwd+bwd Msamples/s", "value": samples_s / 1e6, "unit": "Msamples/s",
@@ -204,6 +206,14 @@ def main():
                          "frac": samples_s / world * C * N * N * BYTES_PER_ELEM["step"] / 1e9 / HBM_PEAK_GBS,
                          "note": "per GPU: samples/s x 20 B/element (whole step incl. launch gaps and small kernels)"},
         }
+        if valu:
+            # the resource these kernels actually saturate first: a wave64 fp32 VALU instruction
+            # holds its SIMD for 4 cycles; 1024 SIMDs at 2.4 GHz
+            floor_b = valu["adi_bwd_kernel"] * 4 / 1024 / 2.4e9 * 1e3
+            floor_f = valu["adi_fwd_kernel"] * 4 / 1024 / 2.4e9 * 1e3
+            out["valu_issue"] = {"note": "SQ_INSTS_VALU per launch (rocprofv3 --pmc, profiles/) x 4 cycles / 1024 SIMDs / 2.4 GHz",
+                                 "adi_bwd_kernel": {"floor_ms": floor_b, "frac": floor_b / bwd_ms},
+                                 "adi_fwd_kernel": {"floor_ms": floor_f, "frac": floor_f / fwd_ms}}
 
     if not a.no_secondary:
         layer2 = build_layer(C, N, steps, dev, rank, mixing=True)
@@ -212,7 +222,7 @@ def main():
         dt2 = timed(layer2, u, gy, k2, 2, dist_on, flat2)
         if rank == 0:
             out["secondary"] = {"config": "same workload with the C x C channel mixing before every step "
-                                          "(cifar10.py:91), unfused: 10 x (mix kernel + 3-sweep ADI launch)",
+                                          "(cifar10.py:91): 10 x (MFMA mix kernel + 3-sweep ADI launch), backward with the fused mixing-gradient kernel",
                                 "value": B * world * k2 / dt2 / 1e6, "unit": "Msamples/s",
                                 "ms_per_step": dt2 / k2 * 1e3}
         del layer2
