@@ -88,6 +88,34 @@ def test_other_variants_vs_oracle(which):
     _compare(layer, lambda a, p: O.adi_forward(a, p, spec), u, gy)
 
 
+@pytest.mark.parametrize("N", [8, 12, 16, 20, 24, 28, 32])
+def test_every_line_length_vs_oracle(N):
+    """One kernel instantiation per supported N (multiples of 4 up to 32): Lie and Strang splits, smoothing,
+    idle lanes of the 32-line wave (N < 32) and a batch that is not a multiple of the planes per iteration."""
+    import cnn_with_pde_amd as P
+    g = torch.Generator().manual_seed(200 + N)
+    lie = quiet(P.LearnableDiffusionLayer, N, 2, 0.03, 1.0, 1.2, 3)
+    _perturb(lie, g, 0.2, 0.4)
+    u = torch.randn(21, 2, N, N, generator=g)
+    gy = torch.randn(21, 2, N, N, generator=g)
+    _compare(lie, lambda a, p: O.adi_forward(a, p, O.cifar2_spec(N, 2, 0.03, 1.0, 1.2, 3)), u, gy)
+    strang = quiet(P.MnistDiffusionLayer, N, 0.01, 1.0, 1.0, 3)           # smooth3, C = 1
+    _perturb(strang, g, 0.2, 0.4)
+    u = torch.randn(5, 1, N, N, generator=g)
+    gy = torch.randn(5, 1, N, N, generator=g)
+    _compare(strang, lambda a, p: O.adi_forward(a, p, O.mnist_spec(N, 0.01, 1.0, 1.0, 3)), u, gy)
+
+
+def test_unsupported_sizes_fail_loudly():
+    """N outside the instantiated set is an error from the C ABI, never a silent other path."""
+    import cnn_with_pde_amd as P
+    from cnn_with_pde_amd._lib import PdeError
+    for N in (6, 30, 36, 64):
+        layer = quiet(P.MnistDiffusionLayer, N).cuda()
+        with pytest.raises(PdeError):
+            layer(torch.zeros(2, 1, N, N, device="cuda"))
+
+
 def test_bf16_io_vs_fp32_oracle():
     """bf16 tensors in and out, fp32 arithmetic inside: compared with the fp32 oracle fed
     the bf16-rounded input, at bf16 resolution."""
@@ -190,6 +218,27 @@ def test_channel_mix_vs_fp64(C, HW):
     assert G.rel_err(out.detach().cpu().view(B, C, HW), ref.detach()) <= TOL
     assert G.rel_err(ud.grad.cpu(), u64.grad) <= TOL
     assert G.rel_err(Md.grad.cpu(), M64.grad) <= TOL
+
+
+@pytest.mark.parametrize("C", [64, 128, 32])
+def test_channel_mix_bf16_io(C):
+    """bf16 tensors through the MFMA mixing kernels (C = 64/128: fused backward), fp32 arithmetic inside."""
+    import cnn_with_pde_amd as P
+    g = torch.Generator().manual_seed(300 + C)
+    B, HW = 3, 1024
+    u = torch.randn(B, C, HW, generator=g).bfloat16()
+    M = torch.eye(C) + 0.05 * torch.randn(C, C, generator=g)
+    go = torch.randn(B, C, HW, generator=g).bfloat16()
+    ud, Md = u.cuda().view(B, C, 32, 32).requires_grad_(True), M.cuda().requires_grad_(True)
+    out = P.channel_mix(ud, Md)
+    assert out.dtype == torch.bfloat16
+    out.backward(go.cuda().view(B, C, 32, 32))
+    u64, M64 = u.double().requires_grad_(True), M.double().requires_grad_(True)
+    ref = torch.matmul(M64, u64)
+    ref.backward(go.double())
+    assert G.rel_err(out.detach().float().cpu().view(B, C, HW), ref.detach()) <= 2e-2
+    assert G.rel_err(ud.grad.float().cpu().view(B, C, HW), u64.grad) <= 2e-2
+    assert G.rel_err(Md.grad.cpu(), M64.grad) <= 1e-4          # fp32 accumulation of bf16 inputs
 
 
 def test_explicit_layers_vs_oracle():
