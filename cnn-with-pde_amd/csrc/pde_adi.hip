@@ -75,22 +75,24 @@ struct FactorArgs {
     PdeSweep sweep[PDE_MAX_SWEEPS];
 };
 
-// One thread per (sweep, channel, line): it factorises its own line (two-sided) and writes its row of
-// every image of the record as nine 16-byte stores.  No LDS, so occupancy is not limited and a
-// 64-thread block (two channels of one sweep) costs nothing to schedule.  The row-layout images
-// (KAPX, MASKX) of a y sweep are NOT transposed through memory: thread h recomputes the
-// coefficient of row h directly from the parameters (three rows for the smoothed variants).
+// One thread per (sweep, channel, HALF line): the two-sided factorisation makes the halves of a line
+// independent up to the junction factor (one lane exchange), so a wave is 32 lines x 2 halves of one
+// channel — the sweep kernels' own layout — and each thread's serial chain (divisions!) is N/2 long.
+// A thread writes its half of every image row as 16-byte stores.  No LDS.  The row-layout images
+// (KAPX, MASKX) of a y sweep are NOT transposed through memory: thread (h, hf) recomputes the
+// coefficients of its half of row h directly from the parameters (three rows for the smoothed variants).
 template <int N>
-__device__ __forceinline__ void store_row(float* dst, const float (&lo)[N / 2], const float (&hi)[N / 2]) {
+__device__ __forceinline__ void store_half_row(float* row, int hf, const float (&v)[N / 2]) {
     // image row = [16 floats: half seen from the low end][16: half seen from the high end][4 pad]
-    float row[kLineStride];
+    float h[kHalfPad];
 #pragma unroll
-    for (int p = 0; p < kLineStride; ++p) row[p] = 0.f;
+    for (int k = 0; k < kHalfPad; ++k) h[k] = 0.f;
 #pragma unroll
-    for (int k = 0; k < N / 2; ++k) { row[k] = lo[k]; row[kHalfPad + k] = hi[k]; }
+    for (int k = 0; k < N / 2; ++k) h[k] = v[k];
+    float4* dst = reinterpret_cast<float4*>(row + hf * kHalfPad);
 #pragma unroll
-    for (int q = 0; q < kLineStride / 4; ++q)
-        reinterpret_cast<float4*>(dst)[q] = make_float4(row[4 * q], row[4 * q + 1], row[4 * q + 2], row[4 * q + 3]);
+    for (int q = 0; q < kHalfPad / 4; ++q) dst[q] = make_float4(h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]);
+    if (hf) *reinterpret_cast<float4*>(row + 2 * kHalfPad) = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 __device__ __forceinline__ float clamp_theta(float th, const FactorArgs& a, bool& pass) {
@@ -101,12 +103,12 @@ __device__ __forceinline__ float clamp_theta(float th, const FactorArgs& a, bool
 }
 
 template <int N>
-__global__ __launch_bounds__(64) void adi_factor_kernel(FactorArgs a) {
+__global__ __launch_bounds__(128) void adi_factor_kernel(FactorArgs a) {
     constexpr int m = N / 2;
     const int pairs = (a.C + 1) / 2;
     const int s = blockIdx.x / pairs;
-    const int c = 2 * (blockIdx.x % pairs) + (threadIdx.x >> 5);
-    const int line = threadIdx.x & 31;
+    const int c = 2 * (blockIdx.x % pairs) + (threadIdx.x >> 6);           // one wave per channel of the pair
+    const int hf = (threadIdx.x >> 5) & 1, line = threadIdx.x & 31;
     if (blockIdx.x == 0 && threadIdx.x < a.S) {   // publish the sweep table
         const int idx = threadIdx.x;
         float tprev = 0.f, tlast = 0.f;
@@ -127,114 +129,112 @@ __global__ __launch_bounds__(64) void adi_factor_kernel(FactorArgs a) {
     float kmax_lane = 0.f;
     const PdeSweep sw = a.sweep[s];
     const bool xax = sw.axis == PDE_AXIS_X;
-    if (c < a.C) {
+    if (c < a.C) {                                   // wave-uniform
         float* rec = a.coef + ((size_t)s * a.C + c) * kRecStride;
         float zero[m];
 #pragma unroll
         for (int k = 0; k < m; ++k) zero[k] = 0.f;
-        if (line >= N) {
-            // idle lines get zero rows: lanes beyond the plane run the same instruction stream on
-            // zeros, so nothing they compute can leak a NaN through a lane exchange
-            rec[kG_Jn + line] = 0.f;
-            store_row<N>(rec + kG_Inv + line * kLineStride, zero, zero);
-            store_row<N>(rec + kG_E + line * kLineStride, zero, zero);
-            store_row<N>(rec + kG_InvB + line * kLineStride, zero, zero);
-            store_row<N>(rec + kG_KapX + line * kLineStride, zero, zero);
-            store_row<N>(rec + kG_MaskX + line * kLineStride, zero, zero);
-        } else {
-            const float* base = xax ? a.ab : a.bb;
-            const float* slope = xax ? a.as : a.bs;
-            const size_t cbase = (size_t)c * N * N;
-            const int st = xax ? 1 : N;                 // stride between consecutive unknowns of my line
-            const int o0 = xax ? line * N : line;
-            const float third = 1.0f / 3.0f;
-            const float one_eps = 1.0f + a.eps, r1e = 1.0f / one_eps;
-            float kap[N];
-            float pass[N];
-            bool differs = false;
-            // theta = clamp(base + slope*t, eps[, max])          mnist_test.py:33-42
+        const bool idle = line >= N;
+        // idle lines get zero rows: lanes beyond the plane run the same instruction stream on zeros, so
+        // nothing they compute can leak a NaN through a lane exchange.  They follow the code below on a
+        // clamped line index (for the lane exchange) and store zeros at the end.
+        const int ln = idle ? N - 1 : line;
+        const float* base = xax ? a.ab : a.bb;
+        const float* slope = xax ? a.as : a.bs;
+        const size_t cbase = (size_t)c * N * N;
+        const int st = xax ? 1 : N;                 // stride between consecutive unknowns of my line
+        const int o0 = xax ? ln * N : ln;
+        const float third = 1.0f / 3.0f;
+        const float one_eps = 1.0f + a.eps, r1e = 1.0f / one_eps;
+        // my unknowns: k = 0..m-1 at global index i(k) = hf ? N-1-k : k; raw theta also one step beyond my
+        // inner end (index m or m-1) for the 3-tap smoothing
+        float th[m + 1], pass[m];
+        bool differs = false;
+        // theta = clamp(base + slope*t, eps[, max])          mnist_test.py:33-42
 #pragma unroll
-            for (int i = 0; i < N; ++i) {
-                const float bs = base[cbase + o0 + i * st], sl = slope[cbase + o0 + i * st];
-                bool ps, ps0;
-                kap[i] = clamp_theta(bs + sl * sw.t, a, ps);
+        for (int k = 0; k <= m; ++k) {
+            const int i = hf ? N - 1 - k : k;
+            const float bs = base[cbase + o0 + i * st], sl = slope[cbase + o0 + i * st];
+            bool ps, ps0;
+            th[k] = clamp_theta(bs + sl * sw.t, a, ps);
+            if (k < m) {
                 (void)clamp_theta(bs + sl * a.t_first[sw.axis], a, ps0);
                 differs |= (ps != ps0);
-                pass[i] = ps ? 1.0f : 0.0f;
+                pass[k] = ps ? 1.0f : 0.0f;
             }
-            if (differs && a.varying) atomicOr(&a.varying[c], 1);
-            if (a.smooth3) {                             // mnist_test.py:135-149 (replicate ends)
-                float prev = kap[0];
-#pragma unroll
-                for (int i = 0; i < N; ++i) {
-                    const float cur = kap[i];
-                    const float nxt = kap[i + 1 < N ? i + 1 : N - 1];
-                    kap[i] = (prev * third + cur * third) + nxt * third;
-                    prev = cur;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-                kap[i] = (kap[i] * sw.delta) / sw.h2;     // coeff = theta*dt/dx**2  mnist_test.py:83
-                kmax_lane = fmaxf(kmax_lane, kap[i]);
-            }
-            // two-sided elimination of (A + eps I): rows i = k (hf 0) and i = N-1-k (hf 1),
-            // den_k = b_k - kap_k * (kap_{k-1}/den_{k-1}) + eps       mnist_test.py:169,177
-            float inv[2][m], ee[2][m], invb[2][m];
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                float e = 0.f;                           // kap_{k-1}/den_{k-1} of the outer neighbour
-#pragma unroll
-                for (int k = 0; k < m; ++k) {
-                    const int i = hf ? N - 1 - k : k;
-                    const float kp = kap[i];
-                    const float b = (k == 0) ? 1.0f + kp : 1.0f + 2.0f * kp;    // Neumann ends, mnist_test.py:88-93
-                    const float den = (b - kp * e) + a.eps;
-                    const float iv = 1.0f / den;
-                    e = kp * iv;
-                    inv[hf][k] = iv;
-                    invb[hf][k] = iv * one_eps;
-                    ee[hf][k] = e;
-                }
-            }
-            rec[kG_Jn + line] = 1.0f / (1.0f - ee[0][m - 1] * ee[1][m - 1]);
-            store_row<N>(rec + kG_Inv + line * kLineStride, inv[0], inv[1]);
-            store_row<N>(rec + kG_E + line * kLineStride, ee[0], ee[1]);
-            store_row<N>(rec + kG_InvB + line * kLineStride, invb[0], invb[1]);
-            // coefficient and clamp mask in ROW layout: row h = line, element (h,w) at half_pos(w)
-            float kx[2][m], mx[2][m];
-            if (xax) {
-#pragma unroll
-                for (int k = 0; k < m; ++k) {
-                    kx[0][k] = kap[k] * r1e;           mx[0][k] = pass[k];
-                    kx[1][k] = kap[N - 1 - k] * r1e;   mx[1][k] = pass[N - 1 - k];
-                }
-            } else {
-                // y sweep: coefficient of row h = line along w, from beta directly (smoothing runs along h)
-                const int h = line;
-                const int hm = h > 0 ? h - 1 : 0, hp = h + 1 < N ? h + 1 : N - 1;
-#pragma unroll
-                for (int w = 0; w < N; ++w) {
-                    bool ps, pd;
-                    float th = clamp_theta(base[cbase + h * N + w] + slope[cbase + h * N + w] * sw.t, a, ps);
-                    if (a.smooth3) {
-                        const float tm = clamp_theta(base[cbase + hm * N + w] + slope[cbase + hm * N + w] * sw.t, a, pd);
-                        const float tp = clamp_theta(base[cbase + hp * N + w] + slope[cbase + hp * N + w] * sw.t, a, pd);
-                        th = (tm * third + th * third) + tp * third;
-                    }
-                    const float kv = ((th * sw.delta) / sw.h2) * r1e;
-                    const int hf = w < m ? 0 : 1, k = w < m ? w : N - 1 - w;
-                    kx[hf][k] = kv;
-                    mx[hf][k] = ps ? 1.0f : 0.0f;
-                }
-            }
-            store_row<N>(rec + kG_KapX + line * kLineStride, kx[0], kx[1]);
-            store_row<N>(rec + kG_MaskX + line * kLineStride, mx[0], mx[1]);
         }
+        if (differs && !idle && a.varying) atomicOr(&a.varying[c], 1);
+        float kap[m];
+        if (a.smooth3) {                             // mnist_test.py:135-149 (replicate ends): prev/next along the line
+#pragma unroll
+            for (int k = 0; k < m; ++k) {
+                const float outer = th[k > 0 ? k - 1 : 0];          // towards my end (replicated at k = 0)
+                const float inner = th[k + 1];
+                const float prev = hf ? inner : outer, nxt = hf ? outer : inner;   // in increasing global index
+                kap[k] = (prev * third + th[k] * third) + nxt * third;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < m; ++k) kap[k] = th[k];
+        }
+#pragma unroll
+        for (int k = 0; k < m; ++k) {
+            kap[k] = (kap[k] * sw.delta) / sw.h2;         // coeff = theta*dt/dx**2  mnist_test.py:83
+            if (!idle) kmax_lane = fmaxf(kmax_lane, kap[k]);
+        }
+        // two-sided elimination of (A + eps I) from my end inwards:
+        // den_k = b_k - kap_k * (kap_{k-1}/den_{k-1}) + eps       mnist_test.py:169,177
+        float inv[m], ee[m], invb[m];
+        {
+            float e = 0.f;                               // kap_{k-1}/den_{k-1} of the outer neighbour
+#pragma unroll
+            for (int k = 0; k < m; ++k) {
+                const float kp = kap[k];
+                const float b = (k == 0) ? 1.0f + kp : 1.0f + 2.0f * kp;    // Neumann ends, mnist_test.py:88-93
+                const float den = (b - kp * e) + a.eps;
+                const float iv = 1.0f / den;
+                e = kp * iv;
+                inv[k] = iv;
+                invb[k] = iv * one_eps;
+                ee[k] = e;
+            }
+        }
+        const float e_other = __shfl_xor(ee[m - 1], 32, 64);
+        const float e_lo = hf ? e_other : ee[m - 1], e_hi = hf ? ee[m - 1] : e_other;
+        if (hf == 0) rec[kG_Jn + line] = idle ? 0.f : 1.0f / (1.0f - e_lo * e_hi);
+        float* row = rec + line * kLineStride;
+        store_half_row<N>(row + kG_Inv, hf, idle ? zero : inv);
+        store_half_row<N>(row + kG_E, hf, idle ? zero : ee);
+        store_half_row<N>(row + kG_InvB, hf, idle ? zero : invb);
+        // coefficient and clamp mask in ROW layout: row h = line, element (h,w) at half_pos(w)
+        float kx[m], mx[m];
+        if (xax) {
+#pragma unroll
+            for (int k = 0; k < m; ++k) { kx[k] = kap[k] * r1e; mx[k] = pass[k]; }
+        } else {
+            // y sweep: coefficient of row h = line along w, from beta directly (smoothing runs along h)
+            const int h = ln;
+            const int hm = h > 0 ? h - 1 : 0, hp = h + 1 < N ? h + 1 : N - 1;
+#pragma unroll
+            for (int k = 0; k < m; ++k) {
+                const int w = hf ? N - 1 - k : k;
+                bool ps, pd;
+                float t0 = clamp_theta(base[cbase + h * N + w] + slope[cbase + h * N + w] * sw.t, a, ps);
+                if (a.smooth3) {
+                    const float tm = clamp_theta(base[cbase + hm * N + w] + slope[cbase + hm * N + w] * sw.t, a, pd);
+                    const float tp = clamp_theta(base[cbase + hp * N + w] + slope[cbase + hp * N + w] * sw.t, a, pd);
+                    t0 = (tm * third + t0 * third) + tp * third;
+                }
+                kx[k] = ((t0 * sw.delta) / sw.h2) * r1e;
+                mx[k] = ps ? 1.0f : 0.0f;
+            }
+        }
+        store_half_row<N>(row + kG_KapX, hf, idle ? zero : kx);
+        store_half_row<N>(row + kG_MaskX, hf, idle ? zero : mx);
     }
     if (a.kmax) {                                    // per-sweep maximum coefficient: one atomic per wave
         for (int o = 32; o > 0; o >>= 1) kmax_lane = fmaxf(kmax_lane, __shfl_xor(kmax_lane, o, 64));
-        if (threadIdx.x == 0) atomicMax((unsigned int*)&a.kmax[s], __float_as_uint(kmax_lane));   // values are > 0
+        if ((threadIdx.x & 63) == 0) atomicMax((unsigned int*)&a.kmax[s], __float_as_uint(kmax_lane));   // values are >= 0
     }
 }
 
@@ -272,6 +272,13 @@ __global__ __launch_bounds__(64) void adi_kmax_kernel(FactorArgs a) {
     }
     for (int o = 32; o > 0; o >>= 1) km = fmaxf(km, __shfl_xor(km, o, 64));
     if (threadIdx.x == 0) atomicMax((unsigned int*)&a.kmax[s], __float_as_uint(km));   // coefficients are > 0
+}
+
+// one launch instead of two hipMemsetAsync (which become three fill kernels of ~4.5 us each)
+__global__ __launch_bounds__(256) void adi_zero_kernel(int* flags, int nflags, float* kmax, int nk) {
+    for (int i = threadIdx.x; i < nflags; i += 256) flags[i] = 0;
+    if (kmax)
+        for (int i = threadIdx.x; i < nk; i += 256) kmax[i] = 0.f;
 }
 
 // ---- parameter-gradient epilogue: one workgroup per channel ------------------------------
@@ -414,7 +421,7 @@ int launch_factor(const PdeAdiDesc* d, const float* ab, const float* bb, const f
     fa.coef = coef; fa.tab = tab; fa.varying = varying; fa.kmax = kmax;
     const dim3 grid(d->num_sweeps * ((d->C + 1) / 2));
     switch (d->N) {
-#define PDE_CASE(NN) case NN: hipLaunchKernelGGL(adi_factor_kernel<NN>, grid, dim3(64), 0, st, fa); break;
+#define PDE_CASE(NN) case NN: hipLaunchKernelGGL(adi_factor_kernel<NN>, grid, dim3(128), 0, st, fa); break;
         PDE_CASE(8) PDE_CASE(12) PDE_CASE(16) PDE_CASE(20) PDE_CASE(24) PDE_CASE(28) PDE_CASE(32)
 #undef PDE_CASE
         default: return PDE_E_UNSUPPORTED_N;
@@ -522,9 +529,7 @@ int pde_adi_forward(const PdeAdiDesc* d, const void* u, void* y, const float* al
     float* coef = static_cast<float*>(workspace);
     SweepTab* tab = reinterpret_cast<SweepTab*>(static_cast<char*>(workspace) + coef_bytes(d));
     int* varying = reinterpret_cast<int*>(static_cast<char*>(workspace) + coef_bytes(d) + tab_bytes());
-    if (hipMemsetAsync(varying, 0, flag_bytes(d), st) != hipSuccess) return PDE_E_LAUNCH;
-    if (kappa_max && hipMemsetAsync(kappa_max, 0, (size_t)d->num_sweeps * sizeof(float), st) != hipSuccess)
-        return PDE_E_LAUNCH;
+    hipLaunchKernelGGL(adi_zero_kernel, dim3(1), dim3(256), 0, st, varying, d->C, kappa_max, d->num_sweeps);
     rc = launch_factor(d, alpha_base, beta_base, alpha_slope, beta_slope, coef, tab, varying, kappa_max, st);
     if (rc != PDE_OK) return rc;
     SweepArgs sa{};
@@ -575,7 +580,7 @@ int pde_adi_backward(const PdeAdiDesc* d, const void* gy, const void* y, const v
         tab = reinterpret_cast<SweepTab*>(const_cast<char*>(fw + coef_bytes(d)));
         varying = reinterpret_cast<int*>(const_cast<char*>(fw + coef_bytes(d) + tab_bytes()));
     } else {
-        if (hipMemsetAsync(varying, 0, flag_bytes(d), st) != hipSuccess) return PDE_E_LAUNCH;
+        hipLaunchKernelGGL(adi_zero_kernel, dim3(1), dim3(256), 0, st, varying, d->C, (float*)nullptr, 0);
         rc = launch_factor(d, alpha_base, beta_base, alpha_slope, beta_slope, coef, tab, varying, nullptr, st);
         if (rc != PDE_OK) return rc;
     }
