@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""End-to-end training step around the MI355X PDE layer, on synthetic data.
+
+Counterpart of the reference's training entry points (model shape of mnist_test.py:221-235 /
+the optimiser recipe of mnist_test.py:282-306: AdamW, cosine schedule, label smoothing, grad clipping),
+with the diffusion layer taken from this package and data parallelism over RCCL:
+
+    python examples/train_synthetic.py --variant mnist --steps 200
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
+        examples/train_synthetic.py --variant cifar10 --steps 200
+
+There is no dataset on the box: every rank draws its shard of a fixed synthetic classification task
+(one smooth random template per class plus noise), so the loss has something to learn and the run is
+reproducible.  One flat bucket (cnn_with_pde_amd.GradBucket) all-reduces every gradient of the model.
+"""
+import argparse
+import contextlib
+import io
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import cnn_with_pde_amd as P  # noqa: E402
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):      # the layers print the reference's ctor banner
+        return fn(*a, **k)
+
+
+class MnistLike(nn.Module):
+    """diff -> flatten -> dropout -> fc -> relu -> dropout -> fc, as mnist_test.py:221-235."""
+    def __init__(self, size=28, classes=10):
+        super().__init__()
+        self.diff = quiet(P.MnistDiffusionLayer, size)
+        self.dropout = nn.Dropout(0.1)
+        self.fc1 = nn.Linear(size * size, 256)
+        self.fc2 = nn.Linear(256, classes)
+
+    def forward(self, x):
+        x = self.diff(x).reshape(x.size(0), -1)
+        x = F.relu(self.fc1(self.dropout(x)))
+        return self.fc2(self.dropout(x))
+
+
+class Cifar10Like(nn.Module):
+    """A stem to `channels` feature maps, the multi-channel implicit layer, pooled linear head."""
+    def __init__(self, size=32, channels=16, classes=10, steps=4):
+        super().__init__()
+        self.stem = nn.Conv2d(3, channels, 3, padding=1)
+        self.pde = quiet(P.EnhancedDiffusionLayer, size, channels, dt=0.01, num_steps=steps)
+        self.head = nn.Linear(channels * 16, classes)
+
+    def forward(self, x):
+        x = self.pde(F.relu(self.stem(x)))
+        return self.head(F.adaptive_avg_pool2d(x, 4).flatten(1))
+
+
+def synthetic_task(variant, classes, gen):
+    c, n = (1, 28) if variant == "mnist" else (3, 32)
+    coarse = torch.randn(classes, c, 7 if n == 28 else 8, 7 if n == 28 else 8, generator=gen)
+    return F.interpolate(coarse, size=(n, n), mode="bilinear", align_corners=False)        # smooth class templates
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--variant", choices=["mnist", "cifar10"], default="mnist")
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
+    ap.add_argument("--lr", type=float, default=1e-3)
+    ap.add_argument("--log-every", type=int, default=50)
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("needs a GPU: the PDE layer has no CPU path")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    torch.manual_seed(0)                                  # identical initial weights on every rank
+    classes = 10
+    model = (MnistLike() if a.variant == "mnist" else Cifar10Like()).to(dev)
+    templates = synthetic_task(a.variant, classes, torch.Generator().manual_seed(7)).to(dev)
+    opt = torch.optim.AdamW(model.parameters(), lr=a.lr, weight_decay=1e-4)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=a.steps)
+    crit = nn.CrossEntropyLoss(label_smoothing=0.1)
+    bucket = P.GradBucket(model.parameters()) if world > 1 else None
+    gen = torch.Generator(device=dev).manual_seed(1000 + rank)          # a different shard per rank
+
+    log, t0 = [], time.perf_counter()
+    for step in range(a.steps):
+        labels = torch.randint(0, classes, (a.batch,), generator=gen, device=dev)
+        x = templates[labels] + 1.0 * torch.randn(a.batch, *templates.shape[1:], generator=gen, device=dev)
+        opt.zero_grad(set_to_none=True)
+        out = model(x)
+        loss = crit(out, labels)
+        loss.backward()
+        if bucket is not None:
+            bucket.allreduce(average=True)               # ONE collective per step
+        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
+        opt.step()
+        sched.step()
+        if step % a.log_every == 0 or step == a.steps - 1:
+            acc = (out.argmax(1) == labels).float().mean().item()
+            log.append({"step": step, "loss": round(loss.item(), 4), "acc": round(acc, 3)})
+            if rank == 0:
+                print(f"step {step:5d}  loss {loss.item():.4f}  acc {acc:.3f}", flush=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        print(json.dumps({"variant": a.variant, "n_gpus": world, "steps": a.steps, "global_batch": a.batch * world,
+                          "samples_per_s": a.batch * world * a.steps / dt, "first": log[0], "last": log[-1]}))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    return log
+
+
+if __name__ == "__main__":
+    main()
