@@ -181,6 +181,19 @@ def main():
     P.timing_enable(False)
     fwd_ms, bwd_ms = f_ms / max(f_n, 1), b_ms / max(b_n, 1)
 
+    # device-copy ceiling measured on this box (report against the spec peak and against this)
+    src = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+    dst = torch.empty_like(src)
+    for _ in range(3):
+        dst.copy_(src)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        dst.copy_(src)
+    torch.cuda.synchronize()
+    copy_gbs = 20 * 2 * src.numel() / (time.perf_counter() - t0) / 1e9
+    del src, dst
+
     out = None
     if rank == 0:
         pmc, valu = None, None
@@ -201,7 +214,7 @@ def main():
                        "global_batch": B * world, "parallelism": f"dp{world}",
                        "grad_allreduce_bytes": (flat.nbytes() if flat is not None else 0)},
             "roofline": {"bound": "hbm", "kernel": "adi_bwd_kernel", "achieved": ach, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc,
+                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc, "copy_ceiling_measured": copy_gbs,
                          "algorithmic_bytes_per_launch": elems * BYTES_PER_ELEM["bwd"], "avg_launch_ms": bwd_ms},
             "roofline_fwd": {"bound": "hbm", "kernel": "adi_fwd_kernel",
                              "achieved": elems * BYTES_PER_ELEM["fwd"] / (fwd_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
