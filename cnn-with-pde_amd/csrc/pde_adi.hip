@@ -483,16 +483,15 @@ int dispatch_fwd(const PdeAdiDesc* d, int split, const SweepArgs& sa, int grid, 
     }, st, true, timed);
 }
 
-int dispatch_bwd(const PdeAdiDesc* d, int split, int masked, const SweepArgs& sa, int grid, size_t lds,
-                 hipStream_t st) {
+int dispatch_bwd(const PdeAdiDesc* d, int split, const SweepArgs& sa, int grid, hipStream_t st) {
     return timed_launch([&]() -> int {
         switch (d->N) {
-#define PDE_CASE(NN) case NN: return adi_launch_bwd_##NN(d->io_dtype, split, masked, &sa, grid, lds, st);
+#define PDE_CASE(NN) case NN: return adi_launch_bwd_##NN(d->io_dtype, split, &sa, grid, st);
             PDE_N_LIST
 #undef PDE_CASE
         }
         return PDE_E_UNSUPPORTED_N;
-    }, st, false, !masked);
+    }, st, false, true);
 }
 
 int count_ckpt(const uint64_t m[2]) { return m ? __builtin_popcountll(m[0]) + __builtin_popcountll(m[1]) : 0; }
@@ -617,12 +616,9 @@ int pde_adi_backward(const PdeAdiDesc* d, const void* gy, const void* y, const v
         if (rc != PDE_OK) return rc;
     }
     const int grid = G * d->C;
-    const size_t lds_fast = (size_t)(2 * kRecBwd + kWaves * kImage) * sizeof(float);
-    const size_t lds_mask = (size_t)(2 * kRecBwdMasked + kWaves * kImage) * sizeof(float);
-    // two launches over the same grid: every workgroup leaves at once unless its channel belongs
-    // to the instantiation (decided on the device by the factor kernel, no host round trip)
-    rc = dispatch_bwd(d, split_of(d), 0, sa, grid, lds_fast, st);
-    if (rc == PDE_OK) rc = dispatch_bwd(d, kSplitAny, 1, sa, grid, lds_mask, st);
+    // one launch, two halves of the grid: fast variant | masked variant; a workgroup leaves at once unless
+    // its channel belongs to its variant (decided on the device by the factor kernel, no host round trip)
+    rc = dispatch_bwd(d, split_of(d), sa, 2 * grid, st);
     if (rc != PDE_OK) return rc;
 
     PgradArgs pa{};

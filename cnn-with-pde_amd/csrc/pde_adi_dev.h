@@ -670,12 +670,12 @@ struct BwdStage {
 };
 
 template <int N, int J, typename IO, bool MASKED, int SPLIT>
-__global__ __launch_bounds__(kThreads) void adi_bwd_kernel(SweepArgs a) {
+__device__ __forceinline__ void adi_bwd_body(const SweepArgs& a, int blk) {
     constexpr int M = Geo<N>::M;
     using ST = BwdStage<MASKED, SPLIT>;
     constexpr int REC = ST::kRec, RECP = ST::kRecPad, SPS = ST::kSps;
     int c, g;
-    block_to_work(blockIdx.x, a.C, a.G, a.xcd_map, c, g);
+    block_to_work(blk, a.C, a.G, a.xcd_map, c, g);
     if ((as_const(a.varying)[c] != 0) != MASKED) return;  // the other instantiation owns this channel
     const ConstTab tab = as_const(a.tab);
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -835,7 +835,7 @@ __global__ __launch_bounds__(kThreads) void adi_bwd_kernel(SweepArgs a) {
                 });
 #ifdef PDE_STAMP
                 // every wave of one workgroup, intervals 2 and 3: work done, DMA landed, barrier passed
-                const bool tl_on = (blockIdx.x == 5 && (t == 2 || t == 3) && lane == 0);
+                const bool tl_on = (blk == 5 && (t == 2 || t == 3) && lane == 0);
                 unsigned long long* tl = reinterpret_cast<unsigned long long*>(a.dbg) + (wave * 2 + (t - 2)) * 3;
                 if (tl_on) tl[0] = stamp();
 #endif
@@ -891,6 +891,17 @@ __global__ __launch_bounds__(kThreads) void adi_bwd_kernel(SweepArgs a) {
         }
         __syncthreads();
     }
+}
+
+// One launch for both variants: blocks [0, C*G) run the fast body (J planes per lane, compile-time step
+// pattern), blocks [C*G, 2*C*G) the MASKED body (per-sweep clamp masks, table-driven); a block whose
+// channel belongs to the other variant — decided on the device by the factor kernel — leaves at once.
+// (Two launches over the same grid cost ~6 us more: the second one's blocks all start, look, and exit.)
+template <int N, int J, typename IO, int SPLIT>
+__global__ __launch_bounds__(kThreads) void adi_bwd_kernel(SweepArgs a) {
+    const int nb = a.C * a.G;
+    if ((int)blockIdx.x < nb) adi_bwd_body<N, J, IO, false, SPLIT>(a, (int)blockIdx.x);
+    else adi_bwd_body<N, 1, IO, true, kSplitAny>(a, (int)blockIdx.x - nb);
 }
 
 }  // namespace

@@ -43,15 +43,19 @@ int fwd_io(int split, const SweepArgs& sa, int grid, size_t lds, hipStream_t st)
 
 template <bool MASKED, int SPLIT>
 constexpr size_t bwd_lds() { return (size_t)(BwdStage<MASKED, SPLIT>::kFloats + kWaves * kImage) * sizeof(float); }
+template <int SPLIT>
+constexpr size_t bwd_lds_dual() {
+    return bwd_lds<false, SPLIT>() > bwd_lds<true, kSplitAny>() ? bwd_lds<false, SPLIT>() : bwd_lds<true, kSplitAny>();
+}
 
+// grid = 2 * C * G: fast and masked variant in one launch (see adi_bwd_kernel)
 template <typename IO>
-int bwd_io(int split, int masked, const SweepArgs& sa, int grid, size_t /*lds*/, hipStream_t st) {
+int bwd_io(int split, const SweepArgs& sa, int grid, hipStream_t st) {
     constexpr int N = PDE_INST_N;
-    if (masked) return launch(adi_bwd_kernel<N, 1, IO, true, kSplitAny>, sa, grid, bwd_lds<true, kSplitAny>(), st);   // rare path
     switch (split) {
-        case kSplitStrang: return launch(adi_bwd_kernel<N, kJBwd, IO, false, kSplitStrang>, sa, grid, bwd_lds<false, kSplitStrang>(), st);
-        case kSplitLie: return launch(adi_bwd_kernel<N, kJBwd, IO, false, kSplitLie>, sa, grid, bwd_lds<false, kSplitLie>(), st);
-        default: return launch(adi_bwd_kernel<N, 1, IO, false, kSplitAny>, sa, grid, bwd_lds<false, kSplitAny>(), st);
+        case kSplitStrang: return launch(adi_bwd_kernel<N, kJBwd, IO, kSplitStrang>, sa, grid, bwd_lds_dual<kSplitStrang>(), st);
+        case kSplitLie: return launch(adi_bwd_kernel<N, kJBwd, IO, kSplitLie>, sa, grid, bwd_lds_dual<kSplitLie>(), st);
+        default: return launch(adi_bwd_kernel<N, 1, IO, kSplitAny>, sa, grid, bwd_lds_dual<kSplitAny>(), st);
     }
 }
 
@@ -62,11 +66,9 @@ int PDE_CAT(adi_launch_fwd_, PDE_INST_N)(int io, int split, const void* args, in
     return io == PDE_IO_F32 ? fwd_io<float>(split, sa, grid, lds, st) : fwd_io<bf16_t>(split, sa, grid, lds, st);
 }
 
-int PDE_CAT(adi_launch_bwd_, PDE_INST_N)(int io, int split, int masked, const void* args, int grid, size_t lds,
-                                         hipStream_t st) {
+int PDE_CAT(adi_launch_bwd_, PDE_INST_N)(int io, int split, const void* args, int grid, hipStream_t st) {
     const SweepArgs& sa = *static_cast<const SweepArgs*>(args);
-    return io == PDE_IO_F32 ? bwd_io<float>(split, masked, sa, grid, lds, st)
-                            : bwd_io<bf16_t>(split, masked, sa, grid, lds, st);
+    return io == PDE_IO_F32 ? bwd_io<float>(split, sa, grid, st) : bwd_io<bf16_t>(split, sa, grid, st);
 }
 
 }  // namespace pde

@@ -13,7 +13,7 @@ constexpr int kJBwd = 2;         // planes per lane in the backward kernel
 // return 0 on success, PDE_E_LAUNCH otherwise
 #define PDE_DECLARE_N(NN)                                                                              \
     int adi_launch_fwd_##NN(int io, int split, const void* args, int grid, size_t lds, hipStream_t st); \
-    int adi_launch_bwd_##NN(int io, int split, int masked, const void* args, int grid, size_t lds, hipStream_t st);
+    int adi_launch_bwd_##NN(int io, int split, const void* args, int grid, hipStream_t st);
 PDE_DECLARE_N(8) PDE_DECLARE_N(12) PDE_DECLARE_N(16) PDE_DECLARE_N(20) PDE_DECLARE_N(24) PDE_DECLARE_N(28) PDE_DECLARE_N(32)
 #undef PDE_DECLARE_N
 }  // namespace pde
