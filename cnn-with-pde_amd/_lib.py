@@ -49,9 +49,18 @@ SIGNATURES = {
     "pde_adi_backward": (C.c_int, [_D, _vp, _vp, _vp, C.POINTER(C.c_uint64), _vp, _fp, _fp, _fp, _fp,
                                    _fp, _fp, _fp, _fp, _vp, _vp, _sz, _vp]),
     "pde_adi_kappa_max": (C.c_int, [_D, _fp, _fp, _fp, _fp, _fp, _vp]),
+    "pde_adi_steps_workspace_bytes": (_sz, [_D, _i32]),
+    "pde_adi_factor_steps": (C.c_int, [_D, _i32, _fp, _fp, _fp, _fp, _fp, _vp, _sz, _vp]),
+    "pde_adi_forward_step": (C.c_int, [_D, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "pde_adi_backward_step_workspace_bytes": (_sz, [_D, _i32, _i32]),
+    "pde_adi_backward_step": (C.c_int, [_D, _i32, _i32, _vp, _vp, _vp, C.POINTER(C.c_uint64), _vp, _vp, _vp, _sz,
+                                        _i32, _vp]),
+    "pde_adi_param_grads": (C.c_int, [_D, _i32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _vp, _vp]),
     "pde_channel_mix_forward": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _fp, _vp, _vp]),
     "pde_channel_mix_backward_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "pde_channel_mix_backward": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _fp, _vp, _fp, _vp, _sz, _vp]),
+    "pde_channel_mix_backward_steps": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _fp, _vp, _fp, _vp, _sz, _i32, _i32,
+                                                 _vp]),
     "pde_explicit5_forward": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _fp, _fp, _f32, _f32, _f32, _f32, _vp, _vp]),
     "pde_explicit5_backward_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "pde_explicit5_backward": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _fp, _fp, _f32, _f32, _f32, _f32,

@@ -70,6 +70,7 @@ struct FactorArgs {
     float* coef;            // [S][C][kRecAll]
     float* kmax;            // optional [S] (atomic max of coeff), may be null
     int C, N, S;
+    int win;                // sweeps per launch window: tab[w] describes sweeps w*win .. w*win+win-1 as ONE launch
     int smooth3, has_max;
     float cmax, eps;
     PdeSweep sweep[PDE_MAX_SWEEPS];
@@ -109,22 +110,30 @@ __global__ __launch_bounds__(128) void adi_factor_kernel(FactorArgs a) {
     const int s = blockIdx.x / pairs;
     const int c = 2 * (blockIdx.x % pairs) + (threadIdx.x >> 6);           // one wave per channel of the pair
     const int hf = (threadIdx.x >> 5) & 1, line = threadIdx.x & 31;
-    if (blockIdx.x == 0 && threadIdx.x < a.S) {   // publish the sweep table
+    if (blockIdx.x == 0 && threadIdx.x < a.S) {   // publish the sweep table(s): one per launch window
         const int idx = threadIdx.x;
+        const int w = idx / a.win, loc = idx % a.win, lo = w * a.win;
+        SweepTab* tab = a.tab + w;
         float tprev = 0.f, tlast = 0.f;
         int first = -1;
         const int ax = a.sweep[idx].axis;
-        for (int q = 0; q < a.S; ++q) {
+        for (int q = lo; q < lo + a.win; ++q) {
             if (a.sweep[q].axis != ax) continue;
-            if (first < 0) first = q;
+            if (first < 0) first = q - lo;
             if (q < idx) tprev = a.sweep[q].t;
             tlast = a.sweep[q].t;
         }
-        a.tab->ysc[idx] = powf(1.0f + a.eps, -(float)(a.S - 1 - idx));
-        a.tab->axis[idx] = ax;
-        a.tab->dts[idx] = a.sweep[idx].t - tprev;
-        a.tab->first_s[ax] = first;
-        a.tab->t_last[ax] = tlast;
+        tab->ysc[loc] = powf(1.0f + a.eps, -(float)(a.win - 1 - loc));
+        tab->axis[loc] = ax;
+        tab->dts[loc] = a.sweep[idx].t - tprev;
+        tab->first_s[ax] = first;
+        tab->t_last[ax] = tlast;
+        if (loc == 0) {                              // an axis the window does not contain
+            const int other = 1 - ax;
+            bool seen = false;
+            for (int q = lo; q < lo + a.win; ++q) seen |= (a.sweep[q].axis == other);
+            if (!seen) { tab->first_s[other] = -1; tab->t_last[other] = 0.f; }
+        }
     }
     float kmax_lane = 0.f;
     const PdeSweep sw = a.sweep[s];
@@ -403,7 +412,7 @@ void fill_factor_args(FactorArgs& fa, const PdeAdiDesc* d, const float* ab, cons
                       const float* bs) {
     fa.tab = nullptr; fa.varying = nullptr; fa.coef = nullptr; fa.kmax = nullptr;
     fa.ab = ab; fa.bb = bb; fa.as = as; fa.bs = bs;
-    fa.C = d->C; fa.N = d->N; fa.S = d->num_sweeps;
+    fa.C = d->C; fa.N = d->N; fa.S = d->num_sweeps; fa.win = d->num_sweeps;
     fa.smooth3 = d->smooth3; fa.has_max = d->has_clamp_max; fa.cmax = d->clamp_max; fa.eps = d->eps;
     fa.t_first[0] = fa.t_first[1] = 0.f;
     bool seen[2] = {false, false};
@@ -415,10 +424,11 @@ void fill_factor_args(FactorArgs& fa, const PdeAdiDesc* d, const float* ab, cons
 }
 
 int launch_factor(const PdeAdiDesc* d, const float* ab, const float* bb, const float* as, const float* bs,
-                  float* coef, SweepTab* tab, int* varying, float* kmax, hipStream_t st) {
+                  float* coef, SweepTab* tab, int* varying, float* kmax, hipStream_t st, int window = 0) {
     FactorArgs fa;
     fill_factor_args(fa, d, ab, bb, as, bs);
     fa.coef = coef; fa.tab = tab; fa.varying = varying; fa.kmax = kmax;
+    if (window > 0) fa.win = window;
     const dim3 grid(d->num_sweeps * ((d->C + 1) / 2));
     switch (d->N) {
 #define PDE_CASE(NN) case NN: hipLaunchKernelGGL(adi_factor_kernel<NN>, grid, dim3(128), 0, st, fa); break;
@@ -496,6 +506,116 @@ int dispatch_bwd(const PdeAdiDesc* d, int split, const SweepArgs& sa, int grid, 
 
 int count_ckpt(const uint64_t m[2]) { return m ? __builtin_popcountll(m[0]) + __builtin_popcountll(m[1]) : 0; }
 
+// ---- launch helpers shared by the whole-schedule entry points and the per-step ones -----------------
+// forward sweeps of `d` (a whole schedule or one step of it) with records/table already in place
+int launch_fwd_sweeps(const PdeAdiDesc* d, const void* u, void* y, const float* coef, const SweepTab* tab,
+                      hipStream_t st) {
+    SweepArgs sa{};
+    sa.in0 = u; sa.out = y; sa.coef = coef; sa.tab = tab;
+    sa.B = d->B; sa.C = d->C; sa.S = d->num_sweeps;
+    sa.G = groups_per_channel(d, kWaves * kJFwd, 16 / kWaves);
+    sa.one_eps = 1.0f + d->eps;
+    sa.xcd_map = use_xcd_map(d);
+    const size_t lds = (size_t)(kRing * kRecFwd + kWaves * kImage) * sizeof(float);
+    return dispatch_fwd(d, split_of(d), sa, sa.G * d->C, lds, st);
+}
+
+struct AxisWeights { float wgt[2], tfirst[2]; bool have[2]; };
+int axis_weights(const PdeAdiDesc* d, AxisWeights& w) {
+    w.wgt[0] = w.wgt[1] = w.tfirst[0] = w.tfirst[1] = 0.f;
+    w.have[0] = w.have[1] = false;
+    for (int s = 0; s < d->num_sweeps; ++s) {
+        const int ax = d->sweep[s].axis;
+        const float v = d->sweep[s].delta / d->sweep[s].h2;
+        if (w.have[ax] && v != w.wgt[ax]) return PDE_E_BADARG;   // one weight per axis (true for every reference variant)
+        if (!w.have[ax]) w.tfirst[ax] = d->sweep[s].t;
+        w.wgt[ax] = v; w.have[ax] = true;
+    }
+    return PDE_OK;
+}
+
+// checkpoint mask -> (count, number of forward sweeps to recompute); PDE_E_BADARG when inconsistent
+int ckpt_plan(const PdeAdiDesc* d, const uint64_t ckpt_mask[2], const void* u, int& nck, int& Sf) {
+    nck = count_ckpt(ckpt_mask);
+    Sf = 0;
+    if (nck) {
+        if (!u) return PDE_E_BADARG;
+        for (int s = 0; s < d->num_sweeps; ++s)
+            if ((ckpt_mask[s >> 6] >> (s & 63)) & 1ull) Sf = s + 1;
+        for (int s = d->num_sweeps; s < 128; ++s)
+            if ((ckpt_mask[s >> 6] >> (s & 63)) & 1ull) return PDE_E_BADARG;    // bit beyond the schedule
+        if (Sf >= d->num_sweeps) return PDE_E_BADARG;      // the last state is y itself
+    }
+    return PDE_OK;
+}
+
+// backward sweeps of `d`: optional checkpoint pre-pass, then the adjoint launch.  Partial gradient sums
+// go to `part` ([G][C][4][image]); with `accumulate` they are ADDED to what is there (per-step launches
+// of one layer call: every workgroup owns its slots, so this is race-free and order-independent).
+int launch_bwd_sweeps(const PdeAdiDesc* d, const void* gy, const void* y, const void* u, const uint64_t ckpt_mask[2],
+                      int nck, int Sf, void* gu, const float* coef, const SweepTab* tab, const int* varying,
+                      float* part, void* dbg, float* ckpt, int G, int accumulate, hipStream_t st) {
+    SweepArgs sa{};
+    sa.in0 = gy; sa.in1 = y; sa.in2 = u; sa.out = gu; sa.coef = coef; sa.part = part; sa.tab = tab;
+    sa.varying = varying; sa.ckpt = ckpt;
+    sa.ck[0] = nck ? ckpt_mask[0] : 0ull; sa.ck[1] = nck ? ckpt_mask[1] : 0ull;
+    sa.Sf = Sf; sa.smooth3 = d->smooth3;
+    sa.xcd_map = use_xcd_map(d);
+    sa.B = d->B; sa.C = d->C; sa.S = d->num_sweeps; sa.G = G;
+    sa.one_eps = 1.0f + d->eps;
+    sa.gu_scale = (float)pow(1.0 + (double)d->eps, -(double)d->num_sweeps);
+    sa.acc_part = accumulate;
+    sa.dbg = dbg;
+    int rc = PDE_OK;
+    if (nck) {
+        // pre-pass: run the forward from u up to the last checkpointed sweep and park those states
+        SweepArgs fa = sa;
+        fa.in0 = u; fa.in1 = nullptr; fa.out = nullptr; fa.part = nullptr;
+        fa.S = Sf;
+        fa.G = groups_per_channel(d, kWaves * kJFwd, 16 / kWaves);
+        const size_t lds_f = (size_t)(kRing * kRecFwd + kWaves * kImage) * sizeof(float);
+        // the pre-pass stops after sweep Sf-1, which need not be a step boundary: look the axes up
+        rc = dispatch_fwd(d, kSplitAny, fa, fa.G * d->C, lds_f, st, false);
+        if (rc != PDE_OK) return rc;
+    }
+    // one launch, two halves of the grid: fast variant | masked variant; a workgroup leaves at once unless
+    // its channel belongs to its variant (decided on the device by the factor kernel, no host round trip)
+    return dispatch_bwd(d, split_of(d), sa, 2 * G * d->C, st);
+}
+
+// parameter gradients from the partial sums; `d` is the WHOLE schedule the sums were taken over
+int launch_pgrad(const PdeAdiDesc* d, const AxisWeights& w, const float* alpha_base, const float* beta_base,
+                 const float* alpha_slope, const float* beta_slope, float* g_alpha_base, float* g_beta_base,
+                 float* g_alpha_slope, float* g_beta_slope, const int* varying, const float* part, int G,
+                 hipStream_t st) {
+    PgradArgs pa{};
+    pa.part = part; pa.ab = alpha_base; pa.bb = beta_base; pa.as = alpha_slope; pa.bs = beta_slope;
+    pa.g_ab = g_alpha_base; pa.g_bb = g_beta_base; pa.g_as = g_alpha_slope; pa.g_bs = g_beta_slope;
+    pa.varying = varying;
+    pa.C = d->C; pa.N = d->N; pa.S = d->num_sweeps; pa.G = G;
+    pa.smooth3 = d->smooth3; pa.has_max = d->has_clamp_max; pa.accumulate = 0;
+    pa.cmax = d->clamp_max; pa.eps = d->eps;
+    // the kernel's sums carry one factor (1+eps) (see pde_common.h, INVB)
+    pa.wx = w.wgt[0] / (1.0f + d->eps); pa.wy = w.wgt[1] / (1.0f + d->eps);
+    pa.t_first[0] = w.tfirst[0]; pa.t_first[1] = w.tfirst[1];
+    pa.have_axis[0] = w.have[0]; pa.have_axis[1] = w.have[1];
+    hipLaunchKernelGGL(adi_pgrad_kernel, dim3(d->C), dim3(1024), 0, st, pa);
+    return check_launch();
+}
+
+// one step (sweeps k*sps .. k*sps+sps-1) of a whole schedule as a launch descriptor of its own
+int step_desc(const PdeAdiDesc* d, int sps, int k, PdeAdiDesc& ds) {
+    const int rc = check_desc(d);
+    if (rc != PDE_OK) return rc;
+    if (sps <= 0 || d->num_sweeps % sps != 0 || k < 0 || k >= d->num_sweeps / sps) return PDE_E_BADARG;
+    ds = *d;
+    ds.num_sweeps = sps;
+    for (int s = 0; s < sps; ++s) ds.sweep[s] = d->sweep[k * sps + s];
+    return PDE_OK;
+}
+// layout of the whole-schedule ("steps") workspace: records of all sweeps | channel flags | one table per step
+size_t steps_tab_offset(const PdeAdiDesc* d) { return coef_bytes(d) + flag_bytes(d); }
+
 }  // namespace
 }  // namespace pde
 
@@ -531,14 +651,7 @@ int pde_adi_forward(const PdeAdiDesc* d, const void* u, void* y, const float* al
     hipLaunchKernelGGL(adi_zero_kernel, dim3(1), dim3(256), 0, st, varying, d->C, kappa_max, d->num_sweeps);
     rc = launch_factor(d, alpha_base, beta_base, alpha_slope, beta_slope, coef, tab, varying, kappa_max, st);
     if (rc != PDE_OK) return rc;
-    SweepArgs sa{};
-    sa.in0 = u; sa.out = y; sa.coef = coef; sa.tab = tab;
-    sa.B = d->B; sa.C = d->C; sa.S = d->num_sweeps;
-    sa.G = groups_per_channel(d, kWaves * kJFwd, 16 / kWaves);
-    sa.one_eps = 1.0f + d->eps;
-    sa.xcd_map = use_xcd_map(d);
-    const size_t lds = (size_t)(kRing * kRecFwd + kWaves * kImage) * sizeof(float);
-    return dispatch_fwd(d, split_of(d), sa, sa.G * d->C, lds, st);
+    return launch_fwd_sweeps(d, u, y, coef, tab, st);
 }
 
 int pde_adi_backward(const PdeAdiDesc* d, const void* gy, const void* y, const void* u, const uint64_t ckpt_mask[2],
@@ -551,16 +664,9 @@ int pde_adi_backward(const PdeAdiDesc* d, const void* gy, const void* y, const v
     if (!gy || !y || !gu || !alpha_base || !beta_base || !alpha_slope || !beta_slope || !g_alpha_base ||
         !g_beta_base || !g_alpha_slope || !g_beta_slope || !workspace)
         return PDE_E_BADARG;
-    const int nck = count_ckpt(ckpt_mask);
-    int Sf = 0;                                            // forward sweeps to recompute
-    if (nck) {
-        if (!u) return PDE_E_BADARG;
-        for (int s = 0; s < d->num_sweeps; ++s)
-            if ((ckpt_mask[s >> 6] >> (s & 63)) & 1ull) Sf = s + 1;
-        for (int s = d->num_sweeps; s < 128; ++s)
-            if ((ckpt_mask[s >> 6] >> (s & 63)) & 1ull) return PDE_E_BADARG;    // bit beyond the schedule
-        if (Sf >= d->num_sweeps) return PDE_E_BADARG;      // the last state is y itself
-    }
+    int nck, Sf;
+    rc = ckpt_plan(d, ckpt_mask, u, nck, Sf);
+    if (rc != PDE_OK) return rc;
     if (workspace_bytes < pde_adi_backward_workspace_bytes(d, nck) || ((uintptr_t)workspace & 15)) return PDE_E_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int G = groups_per_channel(d, kWaves * kJBwd, 8 / kWaves);
@@ -583,57 +689,102 @@ int pde_adi_backward(const PdeAdiDesc* d, const void* gy, const void* y, const v
         rc = launch_factor(d, alpha_base, beta_base, alpha_slope, beta_slope, coef, tab, varying, nullptr, st);
         if (rc != PDE_OK) return rc;
     }
-
-    SweepArgs sa{};
-    sa.in0 = gy; sa.in1 = y; sa.in2 = u; sa.out = gu; sa.coef = coef; sa.part = part; sa.tab = tab;
-    sa.varying = varying; sa.ckpt = ckpt;
-    sa.ck[0] = nck ? ckpt_mask[0] : 0ull; sa.ck[1] = nck ? ckpt_mask[1] : 0ull;
-    sa.Sf = Sf; sa.smooth3 = d->smooth3;
-    sa.xcd_map = use_xcd_map(d);
-    sa.B = d->B; sa.C = d->C; sa.S = d->num_sweeps; sa.G = G;
-    sa.one_eps = 1.0f + d->eps;
-    sa.gu_scale = (float)pow(1.0 + (double)d->eps, -(double)d->num_sweeps);
-    sa.dbg = dbg;
-    float wgt[2] = {0.f, 0.f};
-    float tfirst[2] = {0.f, 0.f};
-    bool have[2] = {false, false};
-    for (int s = 0; s < d->num_sweeps; ++s) {
-        const int ax = d->sweep[s].axis;
-        const float w = d->sweep[s].delta / d->sweep[s].h2;
-        if (have[ax] && w != wgt[ax]) return PDE_E_BADARG;   // one weight per axis (true for every reference variant)
-        if (!have[ax]) tfirst[ax] = d->sweep[s].t;
-        wgt[ax] = w; have[ax] = true;
-    }
-    if (nck) {
-        // pre-pass: run the forward from u up to the last checkpointed sweep and park those states
-        SweepArgs fa = sa;
-        fa.in0 = u; fa.in1 = nullptr; fa.out = nullptr; fa.part = nullptr;
-        fa.S = Sf;
-        fa.G = groups_per_channel(d, kWaves * kJFwd, 16 / kWaves);
-        const size_t lds_f = (size_t)(kRing * kRecFwd + kWaves * kImage) * sizeof(float);
-        // the pre-pass stops after sweep Sf-1, which need not be a step boundary: look the axes up
-        rc = dispatch_fwd(d, kSplitAny, fa, fa.G * d->C, lds_f, st, false);
-        if (rc != PDE_OK) return rc;
-    }
-    const int grid = G * d->C;
-    // one launch, two halves of the grid: fast variant | masked variant; a workgroup leaves at once unless
-    // its channel belongs to its variant (decided on the device by the factor kernel, no host round trip)
-    rc = dispatch_bwd(d, split_of(d), sa, 2 * grid, st);
+    AxisWeights w;
+    rc = axis_weights(d, w);
     if (rc != PDE_OK) return rc;
+    rc = launch_bwd_sweeps(d, gy, y, u, ckpt_mask, nck, Sf, gu, coef, tab, varying, part, dbg, ckpt, G, 0, st);
+    if (rc != PDE_OK) return rc;
+    return launch_pgrad(d, w, alpha_base, beta_base, alpha_slope, beta_slope, g_alpha_base, g_beta_base, g_alpha_slope,
+                        g_beta_slope, varying, part, G, st);
+}
 
-    PgradArgs pa{};
-    pa.part = part; pa.ab = alpha_base; pa.bb = beta_base; pa.as = alpha_slope; pa.bs = beta_slope;
-    pa.g_ab = g_alpha_base; pa.g_bb = g_beta_base; pa.g_as = g_alpha_slope; pa.g_bs = g_beta_slope;
-    pa.varying = varying;
-    pa.C = d->C; pa.N = d->N; pa.S = d->num_sweeps; pa.G = G;
-    pa.smooth3 = d->smooth3; pa.has_max = d->has_clamp_max; pa.accumulate = 0;
-    pa.cmax = d->clamp_max; pa.eps = d->eps;
-    // the kernel's sums carry one factor (1+eps) (see pde_common.h, INVB)
-    pa.wx = wgt[0] / (1.0f + d->eps); pa.wy = wgt[1] / (1.0f + d->eps);
-    pa.t_first[0] = tfirst[0]; pa.t_first[1] = tfirst[1];
-    pa.have_axis[0] = have[0]; pa.have_axis[1] = have[1];
-    hipLaunchKernelGGL(adi_pgrad_kernel, dim3(d->C), dim3(1024), 0, st, pa);
-    return check_launch();
+// ---- one layer call as a sequence of per-step launches (layers with a channel operator between the steps) ----
+size_t pde_adi_steps_workspace_bytes(const PdeAdiDesc* d, int32_t sweeps_per_step) {
+    if (check_desc(d) != PDE_OK || sweeps_per_step <= 0 || d->num_sweeps % sweeps_per_step) return 0;
+    return steps_tab_offset(d) + align_up((size_t)(d->num_sweeps / sweeps_per_step) * sizeof(SweepTab), 256);
+}
+
+int pde_adi_factor_steps(const PdeAdiDesc* d, int32_t sweeps_per_step, const float* alpha_base, const float* beta_base,
+                         const float* alpha_slope, const float* beta_slope, float* kappa_max, void* steps_workspace,
+                         size_t workspace_bytes, void* stream) {
+    int rc = check_desc(d);
+    if (rc != PDE_OK) return rc;
+    if (!alpha_base || !beta_base || !alpha_slope || !beta_slope || !steps_workspace) return PDE_E_BADARG;
+    const size_t need = pde_adi_steps_workspace_bytes(d, sweeps_per_step);
+    if (need == 0) return PDE_E_BADARG;
+    if (workspace_bytes < need || ((uintptr_t)steps_workspace & 15)) return PDE_E_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char* ws = static_cast<char*>(steps_workspace);
+    float* coef = reinterpret_cast<float*>(ws);
+    int* varying = reinterpret_cast<int*>(ws + coef_bytes(d));
+    SweepTab* tabs = reinterpret_cast<SweepTab*>(ws + steps_tab_offset(d));
+    hipLaunchKernelGGL(adi_zero_kernel, dim3(1), dim3(256), 0, st, varying, d->C, kappa_max, d->num_sweeps);
+    return launch_factor(d, alpha_base, beta_base, alpha_slope, beta_slope, coef, tabs, varying, kappa_max, st,
+                         sweeps_per_step);
+}
+
+int pde_adi_forward_step(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t step, const void* u, void* y,
+                         const void* steps_workspace, void* stream) {
+    PdeAdiDesc ds;
+    int rc = step_desc(d, sweeps_per_step, step, ds);
+    if (rc != PDE_OK) return rc;
+    if (!u || !y || !steps_workspace) return PDE_E_BADARG;
+    const char* ws = static_cast<const char*>(steps_workspace);
+    const float* coef = reinterpret_cast<const float*>(ws) + (size_t)step * sweeps_per_step * d->C * kRecStride;
+    const SweepTab* tab = reinterpret_cast<const SweepTab*>(ws + steps_tab_offset(d)) + step;
+    return launch_fwd_sweeps(&ds, u, y, coef, tab, static_cast<hipStream_t>(stream));
+}
+
+size_t pde_adi_backward_step_workspace_bytes(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t num_checkpoints) {
+    PdeAdiDesc ds;
+    if (step_desc(d, sweeps_per_step, 0, ds) != PDE_OK || num_checkpoints < 0) return 0;
+    const int G = groups_per_channel(&ds, kWaves * kJBwd, 8 / kWaves);
+    return align_up((size_t)G * d->C * 4 * kImage * sizeof(float), 256) + 512 +
+           align_up((size_t)num_checkpoints * d->B * d->C * d->N * d->N * sizeof(float), 256);
+}
+
+int pde_adi_backward_step(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t step, const void* gy, const void* y,
+                          const void* u, const uint64_t ckpt_mask[2], void* gu, const void* steps_workspace,
+                          void* workspace, size_t workspace_bytes, int32_t accumulate, void* stream) {
+    PdeAdiDesc ds;
+    int rc = step_desc(d, sweeps_per_step, step, ds);
+    if (rc != PDE_OK) return rc;
+    if (!gy || !y || !gu || !steps_workspace || !workspace) return PDE_E_BADARG;
+    int nck, Sf;
+    rc = ckpt_plan(&ds, ckpt_mask, u, nck, Sf);
+    if (rc != PDE_OK) return rc;
+    if (workspace_bytes < pde_adi_backward_step_workspace_bytes(d, sweeps_per_step, nck) || ((uintptr_t)workspace & 15))
+        return PDE_E_WORKSPACE;
+    const int G = groups_per_channel(&ds, kWaves * kJBwd, 8 / kWaves);
+    const char* fw = static_cast<const char*>(steps_workspace);
+    const float* coef = reinterpret_cast<const float*>(fw) + (size_t)step * sweeps_per_step * d->C * kRecStride;
+    const int* varying = reinterpret_cast<const int*>(fw + coef_bytes(d));
+    const SweepTab* tab = reinterpret_cast<const SweepTab*>(fw + steps_tab_offset(d)) + step;
+    char* ws = static_cast<char*>(workspace);
+    float* part = reinterpret_cast<float*>(ws);           ws += align_up((size_t)G * d->C * 4 * kImage * sizeof(float), 256);
+    void* dbg = ws;                                       ws += 512;
+    float* ckpt = reinterpret_cast<float*>(ws);
+    return launch_bwd_sweeps(&ds, gy, y, u, ckpt_mask, nck, Sf, gu, coef, tab, varying, part, dbg, ckpt, G,
+                             accumulate != 0, static_cast<hipStream_t>(stream));
+}
+
+int pde_adi_param_grads(const PdeAdiDesc* d, int32_t sweeps_per_step, const float* alpha_base, const float* beta_base,
+                        const float* alpha_slope, const float* beta_slope, float* g_alpha_base, float* g_beta_base,
+                        float* g_alpha_slope, float* g_beta_slope, const void* steps_workspace, const void* workspace,
+                        void* stream) {
+    PdeAdiDesc ds;
+    int rc = step_desc(d, sweeps_per_step, 0, ds);
+    if (rc != PDE_OK) return rc;
+    if (!alpha_base || !beta_base || !alpha_slope || !beta_slope || !g_alpha_base || !g_beta_base || !g_alpha_slope ||
+        !g_beta_slope || !steps_workspace || !workspace)
+        return PDE_E_BADARG;
+    AxisWeights w;
+    rc = axis_weights(d, w);                               // over the whole schedule
+    if (rc != PDE_OK) return rc;
+    const int G = groups_per_channel(&ds, kWaves * kJBwd, 8 / kWaves);
+    const int* varying = reinterpret_cast<const int*>(static_cast<const char*>(steps_workspace) + coef_bytes(d));
+    return launch_pgrad(d, w, alpha_base, beta_base, alpha_slope, beta_slope, g_alpha_base, g_beta_base, g_alpha_slope,
+                        g_beta_slope, varying, static_cast<const float*>(workspace), G, static_cast<hipStream_t>(stream));
 }
 
 int pde_adi_kappa_max(const PdeAdiDesc* d, const float* alpha_base, const float* beta_base, const float* alpha_slope,

@@ -53,6 +53,7 @@ struct SweepArgs {
     int B, C, S, G;
     float one_eps;          // 1 + eps
     float gu_scale;         // bwd: (1+eps)^-S
+    int acc_part;           // bwd: add the partial gradient sums to what `part` holds (per-step launches)
     void* dbg;              // diagnostic builds only
 };
 
@@ -887,7 +888,7 @@ __device__ __forceinline__ void adi_bwd_body(const SweepArgs& a, int blk) {
             float sum = 0.f;
 #pragma unroll
             for (int w = 0; w < kWaves; ++w) sum += tbuf[w * kImage + e];
-            dst[arr * kImage + e] = sum;
+            dst[arr * kImage + e] = a.acc_part ? dst[arr * kImage + e] + sum : sum;
         }
         __syncthreads();
     }

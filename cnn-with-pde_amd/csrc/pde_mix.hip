@@ -65,7 +65,7 @@ constexpr int kT = 32;    // output tile edge
 constexpr int kK = 64;    // pixels per LDS chunk
 template <typename IO>
 __global__ __launch_bounds__(256) void mix_gm_kernel(const IO* __restrict__ u, const IO* __restrict__ g,
-                                                     float* __restrict__ part, int B, int C, int HW, int nsplit) {
+                                                     float* __restrict__ part, int B, int C, int HW, int nsplit, int acc) {
     __shared__ float sg[kK][kT + 1];
     __shared__ float su[kK][kT + 1];
     const int tiles = (C + kT - 1) / kT;
@@ -99,10 +99,8 @@ __global__ __launch_bounds__(256) void mix_gm_kernel(const IO* __restrict__ u, c
     }
     float* dst = part + (size_t)split * C * C;
     const int i = ti * kT + oi, j = tj * kT + oj;
-    if (i < C && j < C) dst[i * C + j] = a00;
-    if (i < C && j + 1 < C) dst[i * C + j + 1] = a01;
-    if (i + 1 < C && j < C) dst[(i + 1) * C + j] = a10;
-    if (i + 1 < C && j + 1 < C) dst[(i + 1) * C + j + 1] = a11;
+    auto put = [&](int ii, int jj2, float v) { if (ii < C && jj2 < C) dst[ii * C + jj2] = acc ? dst[ii * C + jj2] + v : v; };
+    put(i, j, a00); put(i, j + 1, a01); put(i + 1, j, a10); put(i + 1, j + 1, a11);
 }
 
 __global__ __launch_bounds__(256) void mix_gm_reduce_kernel(const float* __restrict__ part, float* __restrict__ gM,
@@ -245,7 +243,8 @@ constexpr int kGmKP = 64;      // pixels per staged chunk
 constexpr int kGmLd = kGmKP + 2; // row stride (floats): even for 8-byte stores, 2*ch+p banks stay distinct
 template <typename IO>
 __global__ __launch_bounds__(256) void mix_gm_mfma_kernel(const IO* __restrict__ u, const IO* __restrict__ g,
-                                                          float* __restrict__ part, int B, int C, int HW, int nsplit) {
+                                                          float* __restrict__ part, int B, int C, int HW, int nsplit,
+                                                          int accp) {
     extern __shared__ __attribute__((aligned(16))) float sm[];   // [2][C][kGmLd]
     float* sg = sm;
     float* su = sm + C * kGmLd;
@@ -319,7 +318,7 @@ template <typename IO, int C, int W, bool WLDS>
 __global__ __launch_bounds__(64 * W) void mix_bwd_fused_kernel(const IO* __restrict__ u, const IO* __restrict__ g,
                                                                const float* __restrict__ M, const float* __restrict__ Mfrag,
                                                                IO* __restrict__ gu, float* __restrict__ part, int B, int HW,
-                                                               int nsplit) {
+                                                               int nsplit, int accp) {
     constexpr int KS = C / 2, T = C / 32, NT = 64 * W;
     constexpr int NTM = T * T / W;                       // gM tiles per wave
     constexpr int NTU = 2 * T / W;                       // gu tiles per wave
@@ -409,7 +408,8 @@ __global__ __launch_bounds__(64 * W) void mix_bwd_fused_kernel(const IO* __restr
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = 32 * it + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            dst[i * C + 32 * jt + jj] = acc_m[t][r];
+            float* o = dst + i * C + 32 * jt + jj;
+            *o = accp ? *o + acc_m[t][r] : acc_m[t][r];
         }
     }
 }
@@ -430,13 +430,13 @@ int fused_splits(int B, int C, int HW) {
 }
 template <typename IO, int C, int W, bool WLDS>
 void launch_fused(const void* u, const void* g, const float* M, void* gu, float* part, int B, int HW, int nsplit,
-                  hipStream_t st) {
+                  int accp, hipStream_t st) {
     const size_t lds = (size_t)((WLDS ? C * C : 0) + 2 * C * kGmLd) * sizeof(float);
     float* frag = part + (size_t)nsplit * C * C;     // behind the partial matrices (workspace sized for it)
     if (!WLDS) hipLaunchKernelGGL(mix_frag_kernel, dim3((C * C + 255) / 256), dim3(256), 0, st, M, frag, C);
     static bool cfg = false;
     if (!cfg) { (void)hipFuncSetAttribute((const void*)mix_bwd_fused_kernel<IO, C, W, WLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); cfg = true; }
-    hipLaunchKernelGGL((mix_bwd_fused_kernel<IO, C, W, WLDS>), dim3(nsplit), dim3(64 * W), lds, st, (const IO*)u, (const IO*)g, M, frag, (IO*)gu, part, B, HW, nsplit);
+    hipLaunchKernelGGL((mix_bwd_fused_kernel<IO, C, W, WLDS>), dim3(nsplit), dim3(64 * W), lds, st, (const IO*)u, (const IO*)g, M, frag, (IO*)gu, part, B, HW, nsplit, accp);
 }
 
 bool mfma_apply_ok(int C, int HW) { return (C % 32) == 0 && C <= 128 && (HW % 4) == 0; }   // W fragments: C*C*4 B of LDS
@@ -503,7 +503,15 @@ size_t pde_channel_mix_backward_workspace_bytes(int32_t B, int32_t C, int32_t HW
 int pde_channel_mix_backward(int32_t B, int32_t C, int32_t HW, int32_t io_dtype, const void* u, const void* gout,
                              const float* M, void* gu, float* gM, void* workspace, size_t workspace_bytes,
                              void* stream) {
-    if (B <= 0 || C <= 0 || HW <= 0 || !u || !gout || !M || !gu || !gM || !workspace) return PDE_E_BADARG;
+    return pde_channel_mix_backward_steps(B, C, HW, io_dtype, u, gout, M, gu, gM, workspace, workspace_bytes, 0, 1, stream);
+}
+
+// The same with the matrix gradient spread over several calls (one per time step of a layer):
+// accumulate = 0 starts the partial sums in `workspace`, 1 adds to them; finalize = 1 reduces them into gM.
+int pde_channel_mix_backward_steps(int32_t B, int32_t C, int32_t HW, int32_t io_dtype, const void* u, const void* gout,
+                                   const float* M, void* gu, float* gM, void* workspace, size_t workspace_bytes,
+                                   int32_t accumulate, int32_t finalize, void* stream) {
+    if (B <= 0 || C <= 0 || HW <= 0 || !u || !gout || !M || !gu || !workspace || (finalize && !gM)) return PDE_E_BADARG;
     if (workspace_bytes < pde_channel_mix_backward_workspace_bytes(B, C, HW)) return PDE_E_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (io_dtype != PDE_IO_F32 && io_dtype != PDE_IO_BF16) return PDE_E_BADARG;
@@ -513,13 +521,13 @@ int pde_channel_mix_backward(int32_t B, int32_t C, int32_t HW, int32_t io_dtype,
     if (mfma_fused_ok(C, HW) && getenv("PDE_MIX_UNFUSED") == nullptr) {
         const int nsplit = fused_splits(B, C, HW);
         if (io_dtype == PDE_IO_F32) {
-            if (C == 64) launch_fused<float, 64, 4, true>(u, gout, M, gu, part, B, HW, nsplit, st);
-            else launch_fused<float, 128, 8, false>(u, gout, M, gu, part, B, HW, nsplit, st);
+            if (C == 64) launch_fused<float, 64, 4, true>(u, gout, M, gu, part, B, HW, nsplit, accumulate, st);
+            else launch_fused<float, 128, 8, false>(u, gout, M, gu, part, B, HW, nsplit, accumulate, st);
         } else {
-            if (C == 64) launch_fused<bf16s, 64, 4, true>(u, gout, M, gu, part, B, HW, nsplit, st);
-            else launch_fused<bf16s, 128, 8, false>(u, gout, M, gu, part, B, HW, nsplit, st);
+            if (C == 64) launch_fused<bf16s, 64, 4, true>(u, gout, M, gu, part, B, HW, nsplit, accumulate, st);
+            else launch_fused<bf16s, 128, 8, false>(u, gout, M, gu, part, B, HW, nsplit, accumulate, st);
         }
-        hipLaunchKernelGGL(mix_gm_reduce_kernel, dim3((C * C + 31) / 32), dim3(256), 0, st, part, gM, C * C, nsplit);
+        if (finalize) hipLaunchKernelGGL(mix_gm_reduce_kernel, dim3((C * C + 31) / 32), dim3(256), 0, st, part, gM, C * C, nsplit);
         return check_launch();
     }
     // gu = M^T gout
@@ -539,20 +547,20 @@ int pde_channel_mix_backward(int32_t B, int32_t C, int32_t HW, int32_t io_dtype,
         if (io_dtype == PDE_IO_F32) {
             static bool cfg = false;
             if (!cfg) { (void)hipFuncSetAttribute((const void*)mix_gm_mfma_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024); cfg = true; }
-            hipLaunchKernelGGL((mix_gm_mfma_kernel<float>), dim3(nsplit), dim3(256), lds, st, (const float*)u, (const float*)gout, part, B, C, HW, nsplit);
+            hipLaunchKernelGGL((mix_gm_mfma_kernel<float>), dim3(nsplit), dim3(256), lds, st, (const float*)u, (const float*)gout, part, B, C, HW, nsplit, accumulate);
         } else {
             static bool cfg = false;
             if (!cfg) { (void)hipFuncSetAttribute((const void*)mix_gm_mfma_kernel<bf16s>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024); cfg = true; }
-            hipLaunchKernelGGL((mix_gm_mfma_kernel<bf16s>), dim3(nsplit), dim3(256), lds, st, (const bf16s*)u, (const bf16s*)gout, part, B, C, HW, nsplit);
+            hipLaunchKernelGGL((mix_gm_mfma_kernel<bf16s>), dim3(nsplit), dim3(256), lds, st, (const bf16s*)u, (const bf16s*)gout, part, B, C, HW, nsplit, accumulate);
         }
     } else {
         nsplit = gm_splits(B, C, HW);
         if (io_dtype == PDE_IO_F32)
             hipLaunchKernelGGL((mix_gm_kernel<float>), dim3(tiles * tiles, nsplit), dim3(256), 0, st, (const float*)u,
-                               (const float*)gout, part, B, C, HW, nsplit);
+                               (const float*)gout, part, B, C, HW, nsplit, accumulate);
         else
             hipLaunchKernelGGL((mix_gm_kernel<bf16s>), dim3(tiles * tiles, nsplit), dim3(256), 0, st, (const bf16s*)u,
-                               (const bf16s*)gout, part, B, C, HW, nsplit);
+                               (const bf16s*)gout, part, B, C, HW, nsplit, accumulate);
     }
     hipLaunchKernelGGL(mix_gm_reduce_kernel, dim3((C * C + 31) / 32), dim3(256), 0, st, part, gM, C * C, nsplit);
     return check_launch();

@@ -14,7 +14,7 @@ import torch
 
 from . import _lib as L
 
-__all__ = ["Sweep", "adi_schedule", "adi_diffuse", "plan_checkpoints", "kappa_max_async", "channel_mix", "explicit5_step", "jacobi_diffuse",
+__all__ = ["Sweep", "adi_schedule", "adi_diffuse", "adi_diffuse_mixed", "plan_checkpoints", "kappa_max_async", "channel_mix", "explicit5_step", "jacobi_diffuse",
            "timing_enable", "timing_read"]
 
 
@@ -200,6 +200,152 @@ class _AdiFn(torch.autograd.Function):
         ctx.fwd_ws = None
         gp = [g.reshape(s) for g, s in zip(gp, ctx.param_shapes)]
         return (gu, *gp, None, None, None, None, None, None)
+
+
+class _AdiMixedFn(torch.autograd.Function):
+    """One call of a layer whose time steps are separated by a channel operator: cifar10.py:84-112 (``mode``
+    "pre": u <- M u, then the step's sweeps) and SVHN.py:55-72 ("post": the sweeps, then u <- K u).
+
+    One factorisation for the whole schedule, then per step one mixing launch and one sweep launch; the
+    backward walks the steps in reverse, accumulating the partial sums of the parameter gradients and of the
+    matrix gradient on the device, and reduces them once at the end (instead of a torch autograd node, a
+    factorisation, a reduction and a gradient-accumulation add per step)."""
+
+    @staticmethod
+    def forward(ctx, u, ab, bb, asl, bsl, M, steps, mode, smooth3, clamp_max, eps, ckpt, kmax_sink):
+        lib = L.load()
+        _require_cuda(u, ab, bb, asl, bsl, M)
+        if u.dim() != 4 or u.shape[2] != u.shape[3]:
+            raise L.PdeError(f"expected (B,C,N,N), got {tuple(u.shape)}")
+        B, Cc, N, _ = u.shape
+        if u.dtype not in (torch.float32, torch.bfloat16):
+            u = u.float()
+        u = u.contiguous()
+        sps, K = len(steps[0]), len(steps)
+        sweeps = tuple(s for st in steps for s in st)
+        p = [_as_chw(t, Cc, N) for t in (ab, bb, asl, bsl)]
+        Mf = M.detach().to(torch.float32).contiguous()
+        d = _make_desc(B, Cc, N, _io_dtype(u), sweeps, smooth3, clamp_max, eps)
+        sws = _workspace(lib.pde_adi_steps_workspace_bytes(C.byref(d), sps), u.device)
+        need_grad = any(ctx.needs_input_grad[:6])
+        want_kmax = need_grad and (ckpt == "auto" or kmax_sink is not None)
+        kdev = torch.empty(len(sweeps), dtype=torch.float32, device=u.device) if want_kmax else None
+        # states[k][0]: output of the step's first operator, states[k][1]: of its second (= input of step k+1)
+        states = torch.empty((K, 2) + tuple(u.shape), dtype=u.dtype, device=u.device)
+        HW = N * N
+        with torch.cuda.device(u.device):
+            st = _stream()
+            L.check(lib.pde_adi_factor_steps(C.byref(d), sps, *[_ptr(t) for t in p], _ptr(kdev), _ptr(sws),
+                                             sws.numel(), st), "pde_adi_factor_steps")
+            cur = u
+            for k in range(K):
+                a_k, b_k = states[k, 0], states[k, 1]
+                if mode == "pre":
+                    L.check(lib.pde_channel_mix_forward(B, Cc, HW, _io_dtype(u), _ptr(cur), _ptr(Mf), _ptr(a_k), st),
+                            "pde_channel_mix_forward")
+                    L.check(lib.pde_adi_forward_step(C.byref(d), sps, k, _ptr(a_k), _ptr(b_k), _ptr(sws), st),
+                            "pde_adi_forward_step")
+                else:
+                    L.check(lib.pde_adi_forward_step(C.byref(d), sps, k, _ptr(cur), _ptr(a_k), _ptr(sws), st),
+                            "pde_adi_forward_step")
+                    L.check(lib.pde_channel_mix_forward(B, Cc, HW, _io_dtype(u), _ptr(a_k), _ptr(Mf), _ptr(b_k), st),
+                            "pde_channel_mix_forward")
+                cur = b_k
+            ctx.kmax_host = ctx.kmax_event = None
+            if want_kmax:
+                host = torch.empty(len(sweeps), dtype=torch.float32, pin_memory=True)
+                host.copy_(kdev, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                ctx.kmax_host, ctx.kmax_event = host, ev
+                if kmax_sink is not None:
+                    kmax_sink.append((host, ev))
+        y = states[K - 1, 1]
+        if need_grad:
+            ctx.save_for_backward(u, states, Mf, *p)
+            ctx.sws = sws
+        ctx.cfg = (steps, mode, smooth3, clamp_max, eps, ckpt)
+        ctx.param_shapes = [t.shape for t in (ab, bb, asl, bsl)]
+        ctx.M_dtype = M.dtype
+        return y.clone() if not need_grad else y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = L.load()
+        u, states, Mf, *p = ctx.saved_tensors
+        steps, mode, smooth3, clamp_max, eps, ckpt = ctx.cfg
+        B, Cc, N, _ = u.shape
+        sps, K, HW = len(steps[0]), len(steps), N * N
+        sweeps = tuple(s for st in steps for s in st)
+        d = _make_desc(B, Cc, N, _io_dtype(u), sweeps, smooth3, clamp_max, eps)
+        if ckpt == "auto":
+            ctx.kmax_event.synchronize()
+            km = ctx.kmax_host.tolist()
+            bits = 0
+            for k in range(K):                           # one step-local mask for every step: the union
+                bits |= plan_checkpoints(km[k * sps:(k + 1) * sps])
+        else:
+            bits = int(ckpt)
+        nck = bin(bits).count("1")
+        mask = (C.c_uint64 * 2)(bits & (2 ** 64 - 1), bits >> 64)
+        ws = _workspace(lib.pde_adi_backward_step_workspace_bytes(C.byref(d), sps, nck), u.device)
+        mws = _workspace(lib.pde_channel_mix_backward_workspace_bytes(B, Cc, HW), u.device)
+        g_in = gy.to(u.dtype).contiguous()               # read only: it may be autograd's own buffer
+        bufs = [torch.empty_like(g_in), torch.empty_like(g_in)]
+
+        def other(cur):                                  # a scratch buffer that is not `cur`
+            return bufs[1] if cur is bufs[0] else bufs[0]
+        g_a = g_in
+        gp = [torch.empty_like(t) for t in p]
+        gM = torch.empty_like(Mf)
+        io = _io_dtype(u)
+        with torch.cuda.device(u.device):
+            st = _stream()
+            for k in range(K - 1, -1, -1):
+                first, last = (k == K - 1), (k == 0)
+                a_k, b_k = states[k, 0], states[k, 1]
+                prev = u if k == 0 else states[k - 1, 1]
+                g_b = other(g_a)
+                g_c = other(g_b)                         # never g_in: that one is only ever read
+                if mode == "pre":                        # step = mix (prev -> a_k), sweeps (a_k -> b_k)
+                    L.check(lib.pde_adi_backward_step(C.byref(d), sps, k, _ptr(g_a), _ptr(b_k), _ptr(a_k if nck else None),
+                                                      mask, _ptr(g_b), _ptr(ctx.sws), _ptr(ws), ws.numel(), 0 if first else 1,
+                                                      st), "pde_adi_backward_step")
+                    L.check(lib.pde_channel_mix_backward_steps(B, Cc, HW, io, _ptr(prev), _ptr(g_b), _ptr(Mf), _ptr(g_c),
+                                                               _ptr(gM), _ptr(mws), mws.numel(), 0 if first else 1,
+                                                               1 if last else 0, st), "pde_channel_mix_backward_steps")
+                else:                                    # step = sweeps (prev -> a_k), mix (a_k -> b_k)
+                    L.check(lib.pde_channel_mix_backward_steps(B, Cc, HW, io, _ptr(a_k), _ptr(g_a), _ptr(Mf), _ptr(g_b),
+                                                               _ptr(gM), _ptr(mws), mws.numel(), 0 if first else 1,
+                                                               1 if last else 0, st), "pde_channel_mix_backward_steps")
+                    L.check(lib.pde_adi_backward_step(C.byref(d), sps, k, _ptr(g_b), _ptr(a_k), _ptr(prev if nck else None),
+                                                      mask, _ptr(g_c), _ptr(ctx.sws), _ptr(ws), ws.numel(), 0 if first else 1,
+                                                      st), "pde_adi_backward_step")
+                g_a = g_c
+            L.check(lib.pde_adi_param_grads(C.byref(d), sps, *[_ptr(t) for t in p], *[_ptr(t) for t in gp], _ptr(ctx.sws),
+                                            _ptr(ws), st), "pde_adi_param_grads")
+        ctx.sws = None
+        gp = [g.reshape(s) for g, s in zip(gp, ctx.param_shapes)]
+        return (g_a, *gp, gM.to(ctx.M_dtype), None, None, None, None, None, None, None)
+
+
+def adi_diffuse_mixed(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff, M, steps, mode: str,
+                      smooth3: bool = False, clamp_max: Optional[float] = None, eps: float = 1e-6, checkpoints="auto",
+                      kmax_sink: Optional[list] = None):
+    """All time steps of a layer with a channel operator ``M`` between them, as one autograd node.
+
+    ``steps``: list of per-step sweep lists (``adi_schedule``); ``mode`` "pre": ``u <- M u`` before every
+    step (cifar10.py:91), "post": after every step (SVHN.py:71).  ``checkpoints``: "auto" or a bit mask
+    relative to a step (bit 0 = state after the step's first sweep), applied to every step."""
+    if mode not in ("pre", "post"):
+        raise ValueError(mode)
+    if u.shape[0] == 0:
+        return _empty_passthrough(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff, M)
+    steps = tuple(tuple(st) for st in steps)
+    if len({len(st) for st in steps}) != 1:
+        raise ValueError("every step must have the same number of sweeps")
+    return _AdiMixedFn.apply(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff, M, steps, mode, bool(smooth3),
+                             clamp_max, float(eps), checkpoints, kmax_sink)
 
 
 def _empty_passthrough(u, *params):

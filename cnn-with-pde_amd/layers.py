@@ -78,6 +78,39 @@ class _AdiBase(nn.Module):
         return F_.adi_diffuse(u, *args, sweeps, checkpoints=ck, **kw)
 
 
+    def _diffuse_mixed(self, u, steps, M, mode):
+        """All steps of a layer with a channel operator between them (functional.adi_diffuse_mixed), with
+        the same lagged choice of checkpoints as ``_diffuse`` (one step-local mask for every step)."""
+        args = (self.alpha_base, self.beta_base, self.alpha_time_coeff, self.beta_time_coeff)
+        kw = dict(smooth3=self._smooth3, clamp_max=self._clamp_max, eps=self.stability_eps)
+        ck = self.checkpoint_policy
+        if ck != "lagged":
+            return F_.adi_diffuse_mixed(u, *args, M, steps, mode, checkpoints=ck, **kw)
+        if not (torch.is_grad_enabled() and (u.requires_grad or M.requires_grad or any(p.requires_grad for p in args))):
+            return F_.adi_diffuse_mixed(u, *args, M, steps, mode, checkpoints=0, **kw)
+        sps = len(steps[0])
+
+        def plan(km):
+            bits = 0
+            for k in range(len(steps)):
+                bits |= F_.plan_checkpoints(km[k * sps:(k + 1) * sps], F_.CKPT_AMAX / 2)
+            return bits
+        cache = self.__dict__.setdefault("_kmax_cache", {})
+        key = ("mixed", len(steps), sps, u.device)
+        old = cache.get(key)
+        if old is None:                                    # first call only: wait for the coefficients
+            flat = [s for st in steps for s in st]
+            host, ev = F_.kappa_max_async(u, *args, flat, **kw)
+            ev.synchronize()
+            old = (host, ev, plan(host.tolist()))
+        elif old[1].query():
+            old = (old[0], old[1], plan(old[0].tolist()))
+        sink = []
+        y = F_.adi_diffuse_mixed(u, *args, M, steps, mode, checkpoints=old[2], kmax_sink=sink, **kw)
+        cache[key] = (sink[0][0], sink[0][1], old[2]) if sink else old
+        return y
+
+
 class MnistDiffusionLayer(_AdiBase):
     """mnist_test.py:11-219.  (B,1,size,size) -> same; Strang split, smoothed coefficients."""
     _smooth3 = True
@@ -145,9 +178,7 @@ class SvhnDiffusionLayer(_AdiBase):
 
     def forward(self, u):
         original_u = u
-        for step in self._schedule():
-            u = self._diffuse(u, step)
-            u = F_.channel_mix(u, self.channel_coupling)
+        u = self._diffuse_mixed(u, self._schedule(), self.channel_coupling, "post")
         s = torch.sigmoid(self.skip_weight)
         return s * original_u + (1 - s) * u
 
@@ -184,10 +215,7 @@ class EnhancedDiffusionLayer(_AdiBase):
         steps = self._schedule()
         if not self.channel_mixing_enabled:
             return self._diffuse(u, [s for step in steps for s in step])
-        for step in steps:
-            u = F_.channel_mix(u, self.channel_mixing)
-            u = self._diffuse(u, step)
-        return u
+        return self._diffuse_mixed(u, steps, self.channel_mixing, "pre")
 
 
 class LearnableDiffusionLayer(EnhancedDiffusionLayer):

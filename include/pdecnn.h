@@ -108,6 +108,37 @@ int pde_adi_kappa_max(const PdeAdiDesc* d,
                       const float* alpha_slope, const float* beta_slope,
                       float* kappa_max, void* stream);
 
+/* ---- K1 as a sequence of per-step launches --------------------------------------------------
+ * The variants with a channel operator between the time steps (cifar10.py:91 mixing before every
+ * step, SVHN.py:71 coupling after every step) cannot run their whole time loop in one launch.
+ * These entry points serve ONE layer call as: one factorisation of the whole schedule, then one
+ * sweep launch per step (`sweeps_per_step` consecutive sweeps of `d`, 3 for Strang, 2 for Lie), the
+ * backward accumulating the parameter-gradient partial sums across its per-step launches so that
+ * pde_adi_param_grads runs once.  `d` is always the descriptor of the WHOLE schedule. */
+size_t pde_adi_steps_workspace_bytes(const PdeAdiDesc* d, int32_t sweeps_per_step);
+/* zero + factorise every sweep, one sweep table per step; kappa_max as in pde_adi_forward */
+int pde_adi_factor_steps(const PdeAdiDesc* d, int32_t sweeps_per_step,
+                         const float* alpha_base, const float* beta_base,
+                         const float* alpha_slope, const float* beta_slope,
+                         float* kappa_max, void* steps_workspace, size_t workspace_bytes, void* stream);
+/* y = sweeps of step `step` applied to u */
+int pde_adi_forward_step(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t step,
+                         const void* u, void* y, const void* steps_workspace, void* stream);
+size_t pde_adi_backward_step_workspace_bytes(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t num_checkpoints);
+/* gu = adjoint of step `step`; ckpt_mask bits are relative to the step (bit 0 = state after its first
+ * sweep).  accumulate = 0 starts the partial sums held in `workspace`, 1 adds to them: use the same
+ * workspace for every step of a call. */
+int pde_adi_backward_step(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t step,
+                          const void* gy, const void* y, const void* u, const uint64_t ckpt_mask[2], void* gu,
+                          const void* steps_workspace, void* workspace, size_t workspace_bytes,
+                          int32_t accumulate, void* stream);
+/* the four parameter gradients from the partial sums accumulated in `workspace` */
+int pde_adi_param_grads(const PdeAdiDesc* d, int32_t sweeps_per_step,
+                        const float* alpha_base, const float* beta_base,
+                        const float* alpha_slope, const float* beta_slope,
+                        float* g_alpha_base, float* g_beta_base, float* g_alpha_slope, float* g_beta_slope,
+                        const void* steps_workspace, const void* workspace, void* stream);
+
 /* ---- channel operators ------------------------------------------ */
 
 /* out[b,i,p] = sum_j M[i,j] u[b,j,p]  — cifar10.py:65-72 apply_channel_mixing and
@@ -122,6 +153,14 @@ int pde_channel_mix_backward(int32_t B, int32_t C, int32_t HW, int32_t io_dtype,
                              const void* u, const void* gout, const float* M,
                              void* gu, float* gM,
                              void* workspace, size_t workspace_bytes, void* stream);
+/* The same with gM spread over several calls that share `workspace` (one per time step of a layer):
+ * accumulate = 0 starts the partial sums, 1 adds to them; finalize = 1 reduces them into gM
+ * (gM may be NULL otherwise). */
+int pde_channel_mix_backward_steps(int32_t B, int32_t C, int32_t HW, int32_t io_dtype,
+                                   const void* u, const void* gout, const float* M,
+                                   void* gu, float* gM,
+                                   void* workspace, size_t workspace_bytes,
+                                   int32_t accumulate, int32_t finalize, void* stream);
 
 /* ---- K2: explicit 5-point layers --------------------------- */
 

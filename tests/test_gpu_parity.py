@@ -201,6 +201,41 @@ def test_generic_schedule_equals_composition():
         assert G.rel_err(q1.grad.cpu(), q2.grad.cpu()) <= TOL
 
 
+@pytest.mark.parametrize("mode,split,ck", [("pre", "strang", 0), ("pre", "lie", 0b1), ("post", "strang", 0b11), ("post", "strang", "auto")])
+def test_mixed_layer_call_equals_per_step_composition(mode, split, ck):
+    """adi_diffuse_mixed (one factorisation, per-step launches, gradients accumulated on the device) against
+    the same steps written as separate autograd nodes (adi_diffuse + channel_mix per step)."""
+    import cnn_with_pde_amd as P
+    from cnn_with_pde_amd import functional as F_
+    g = torch.Generator().manual_seed(77)
+    B, C, N, K = 9, 5, 32, 4
+    steps = P.adi_schedule(0.05, 1.0, 1.0, K, split)
+    mk = lambda: [(1 + 0.2 * torch.randn(C, N, N, generator=g)).cuda().requires_grad_(True) for _ in range(2)] + \
+                 [(0.5 * torch.randn(C, N, N, generator=g)).cuda().requires_grad_(True) for _ in range(2)]
+    p1 = mk()
+    p2 = [t.detach().clone().requires_grad_(True) for t in p1]
+    M1 = (torch.eye(C) + 0.1 * torch.randn(C, C, generator=g)).cuda().requires_grad_(True)
+    M2 = M1.detach().clone().requires_grad_(True)
+    u = torch.randn(B, C, N, N, generator=g).cuda()
+    gy = torch.randn(B, C, N, N, generator=g).cuda()
+    u1 = u.clone().requires_grad_(True)
+    y1 = F_.adi_diffuse_mixed(u1, *p1, M1, steps, mode, smooth3=True, checkpoints=ck)
+    y1.backward(gy)
+    u2 = u.clone().requires_grad_(True)
+    v = u2
+    for st in steps:
+        if mode == "pre":
+            v = P.adi_diffuse(P.channel_mix(v, M2), *p2, st, smooth3=True, checkpoints="auto")
+        else:
+            v = P.channel_mix(P.adi_diffuse(v, *p2, st, smooth3=True, checkpoints="auto"), M2)
+    v.backward(gy)
+    assert G.rel_err(y1.detach().cpu(), v.detach().cpu()) <= 2e-6
+    assert G.rel_err(u1.grad.cpu(), u2.grad.cpu()) <= 5e-6
+    assert G.rel_err(M1.grad.cpu(), M2.grad.cpu()) <= 1e-5
+    for q1, q2 in zip(p1, p2):
+        assert G.rel_err(q1.grad.cpu(), q2.grad.cpu()) <= 1e-5
+
+
 @pytest.mark.parametrize("C,HW", [(3, 1024), (64, 1024), (7, 49), (32, 784), (128, 256), (96, 64)])
 def test_channel_mix_vs_fp64(C, HW):
     import cnn_with_pde_amd as P
