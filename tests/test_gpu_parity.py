@@ -310,6 +310,32 @@ def test_explicit_layers_vs_oracle():
     _compare(pl, lambda a, p: O.emotion_forward(a, p, Nx=40, Ny=40, T=0.004), u, gy, tol=2e-4)
 
 
+@pytest.mark.parametrize("amp_dtype", [torch.float16, torch.bfloat16])
+def test_inside_autocast(amp_dtype):
+    """cifar10.py:458-467 trains under autocast: a conv in front hands the layer a half tensor.  fp16 is
+    computed in fp32 (as the reference's elementwise ops are), bf16 is taken as I/O type; gradients reach
+    the conv and the layer's parameters either way."""
+    import cnn_with_pde_amd as P
+    torch.manual_seed(3)
+    conv = torch.nn.Conv2d(3, 4, 3, padding=1).cuda()
+    layer = quiet(P.EnhancedDiffusionLayer, 32, 4, dt=0.01, num_steps=2).cuda()
+    x = torch.randn(6, 3, 32, 32, device="cuda")
+    with torch.autocast("cuda", dtype=amp_dtype):
+        h = conv(x)
+        assert h.dtype == amp_dtype
+        y = layer(h)
+        loss = y.float().square().mean()
+    loss.backward()
+    assert y.dtype in (torch.float32, amp_dtype) and torch.isfinite(y.float()).all()
+    assert conv.weight.grad is not None and torch.isfinite(conv.weight.grad).all() and conv.weight.grad.abs().max() > 0
+    for n, p in layer.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), n
+    # against the same computation without autocast, at half precision resolution
+    h32 = conv(x).detach()
+    y32 = layer(h32)
+    assert G.rel_err(y.detach().float().cpu(), y32.detach().cpu()) <= (2e-2 if amp_dtype == torch.bfloat16 else 5e-3)
+
+
 def test_empty_batch_passes_through():
     """B = 0 (the last, empty shard of a ragged split): the reference's torch ops return an empty tensor
     and zero parameter gradients; so do the layers, without a launch."""
