@@ -14,17 +14,20 @@
 namespace pde {
 namespace {
 
+// The dynamic-LDS limit is a per-device attribute of the kernel: set it once per (kernel, device).
 template <typename K>
 int launch(K kernel, const SweepArgs& sa, int grid, size_t lds, hipStream_t st) {
     static std::mutex mu;
-    static bool configured = false;                 // one static per kernel instantiation
+    static unsigned long long configured = 0;       // bit d: done on device d (one static per kernel instantiation)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PDE_E_LAUNCH;
     {
         std::lock_guard<std::mutex> lk(mu);
-        if (!configured) {
+        if (!((configured >> dev) & 1ull)) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds) != hipSuccess)
                 return PDE_E_LAUNCH;
-            configured = true;
+            configured |= 1ull << dev;
         }
     }
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), lds, st, sa);

@@ -15,6 +15,16 @@
 namespace pde {
 namespace {
 
+// dynamic-LDS limit: a per-device attribute of a kernel, set once per (kernel, device)
+inline void ensure_lds(const void* kernel, int bytes, unsigned long long& done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
+    if (!((done >> dev) & 1ull)) {
+        (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        done |= 1ull << dev;
+    }
+}
+
 template <typename IO> struct Io;
 template <> struct Io<float> {
     __device__ static __forceinline__ float ld(const float* p) { return *p; }
@@ -434,8 +444,8 @@ void launch_fused(const void* u, const void* g, const float* M, void* gu, float*
     const size_t lds = (size_t)((WLDS ? C * C : 0) + 2 * C * kGmLd) * sizeof(float);
     float* frag = part + (size_t)nsplit * C * C;     // behind the partial matrices (workspace sized for it)
     if (!WLDS) hipLaunchKernelGGL(mix_frag_kernel, dim3((C * C + 255) / 256), dim3(256), 0, st, M, frag, C);
-    static bool cfg = false;
-    if (!cfg) { (void)hipFuncSetAttribute((const void*)mix_bwd_fused_kernel<IO, C, W, WLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); cfg = true; }
+    static unsigned long long cfg = 0;
+    ensure_lds((const void*)mix_bwd_fused_kernel<IO, C, W, WLDS>, (int)lds, cfg);
     hipLaunchKernelGGL((mix_bwd_fused_kernel<IO, C, W, WLDS>), dim3(nsplit), dim3(64 * W), lds, st, (const IO*)u, (const IO*)g, M, frag, (IO*)gu, part, B, HW, nsplit, accp);
 }
 
@@ -462,12 +472,12 @@ int launch_apply_mfma(int B, int C, int HW, int io, const void* u, const float* 
     long grid = (nblk + 3) / 4;
     if (grid > 1024) grid = 1024;
     if (io == PDE_IO_F32) {
-        static bool cfg = false;
-        if (!cfg) { (void)hipFuncSetAttribute((const void*)mix_apply_mfma_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); cfg = true; }
+        static unsigned long long cfg = 0;
+        ensure_lds((const void*)mix_apply_mfma_kernel<float>, 65536, cfg);
         hipLaunchKernelGGL((mix_apply_mfma_kernel<float>), dim3((unsigned)grid), dim3(256), lds, st, (const float*)u, M, (float*)out, B, C, HW, trans);
     } else {
-        static bool cfg = false;
-        if (!cfg) { (void)hipFuncSetAttribute((const void*)mix_apply_mfma_kernel<bf16s>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); cfg = true; }
+        static unsigned long long cfg = 0;
+        ensure_lds((const void*)mix_apply_mfma_kernel<bf16s>, 65536, cfg);
         hipLaunchKernelGGL((mix_apply_mfma_kernel<bf16s>), dim3((unsigned)grid), dim3(256), lds, st, (const bf16s*)u, M, (bf16s*)out, B, C, HW, trans);
     }
     return check_launch();
@@ -545,12 +555,12 @@ int pde_channel_mix_backward_steps(int32_t B, int32_t C, int32_t HW, int32_t io_
         nsplit = gm_mfma_splits(B, HW);
         const size_t lds = (size_t)2 * C * kGmLd * sizeof(float);
         if (io_dtype == PDE_IO_F32) {
-            static bool cfg = false;
-            if (!cfg) { (void)hipFuncSetAttribute((const void*)mix_gm_mfma_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024); cfg = true; }
+            static unsigned long long cfg = 0;
+        ensure_lds((const void*)mix_gm_mfma_kernel<float>, 72 * 1024, cfg);
             hipLaunchKernelGGL((mix_gm_mfma_kernel<float>), dim3(nsplit), dim3(256), lds, st, (const float*)u, (const float*)gout, part, B, C, HW, nsplit, accumulate);
         } else {
-            static bool cfg = false;
-            if (!cfg) { (void)hipFuncSetAttribute((const void*)mix_gm_mfma_kernel<bf16s>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024); cfg = true; }
+            static unsigned long long cfg = 0;
+        ensure_lds((const void*)mix_gm_mfma_kernel<bf16s>, 72 * 1024, cfg);
             hipLaunchKernelGGL((mix_gm_mfma_kernel<bf16s>), dim3(nsplit), dim3(256), lds, st, (const bf16s*)u, (const bf16s*)gout, part, B, C, HW, nsplit, accumulate);
         }
     } else {
