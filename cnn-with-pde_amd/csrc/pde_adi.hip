@@ -516,7 +516,7 @@ int launch_fwd_sweeps(const PdeAdiDesc* d, const void* u, void* y, const float* 
     sa.G = groups_per_channel(d, kWaves * kJFwd, 16 / kWaves);
     sa.one_eps = 1.0f + d->eps;
     sa.xcd_map = use_xcd_map(d);
-    const size_t lds = (size_t)(kRing * kRecFwd + kWaves * kImage) * sizeof(float);
+    const size_t lds = (size_t)(kRing * kRecFwdPad + kWaves * kImage) * sizeof(float);
     return dispatch_fwd(d, split_of(d), sa, sa.G * d->C, lds, st);
 }
 
@@ -573,7 +573,7 @@ int launch_bwd_sweeps(const PdeAdiDesc* d, const void* gy, const void* y, const 
         fa.in0 = u; fa.in1 = nullptr; fa.out = nullptr; fa.part = nullptr;
         fa.S = Sf;
         fa.G = groups_per_channel(d, kWaves * kJFwd, 16 / kWaves);
-        const size_t lds_f = (size_t)(kRing * kRecFwd + kWaves * kImage) * sizeof(float);
+        const size_t lds_f = (size_t)(kRing * kRecFwdPad + kWaves * kImage) * sizeof(float);
         // the pre-pass stops after sweep Sf-1, which need not be a step boundary: look the axes up
         rc = dispatch_fwd(d, kSplitAny, fa, fa.G * d->C, lds_f, st, false);
         if (rc != PDE_OK) return rc;

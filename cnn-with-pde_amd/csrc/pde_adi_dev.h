@@ -459,8 +459,8 @@ template <int N, int J, typename IO, int SPLIT>
 __global__ __launch_bounds__(kThreads) void adi_fwd_kernel(SweepArgs a) {
     constexpr int M = Geo<N>::M;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* cbuf = smem;                                   // [kRing][kRecFwd]
-    float* tbuf = smem + kRing * kRecFwd;                 // [kWaves][kImage]
+    float* cbuf = smem;                                   // [kRing][kRecFwdPad]
+    float* tbuf = smem + kRing * kRecFwdPad;              // [kWaves][kImage]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hf = lane >> 5, l = lane & 31;
     int c, g;
@@ -479,19 +479,26 @@ __global__ __launch_bounds__(kThreads) void adi_fwd_kernel(SweepArgs a) {
 
     // rows >= N of the wave images are never written: zero them once so idle lanes read zeros
     for (int e = tid; e < kWaves * kImage; e += kThreads) tbuf[e] = 0.f;
-    Staged stg;
-    stg.r0 = stg.r1 = stg.r2 = stg.r3 = stg.r4 = make_float4(0.f, 0.f, 0.f, 0.f);
     // Sweeps are numbered along the whole job of this workgroup (item i = sweep i % S of chunk i / S).
     // In barrier interval t the lower waves run item t from ring slot t % 3, the upper waves item
-    // t-1 from slot (t-1) % 3, and every thread stages its pieces of item t+1 into slot (t+1) % 3.
+    // t-1 from slot (t-1) % 3, and every wave brings its pieces of item t+1 into slot (t+1) % 3 by
+    // LDS-DMA (no registers: a record staged through VGPRs costs a VMEM return and a ds_write per dword,
+    // 15 % of everything this kernel moves through the register file).
     int cur = 0;                                          // ring slot of my current item
-    auto rec_of = [&](int s) { return a.coef + ((size_t)s * a.C + c) * kRecStride + kG_Inv; };
-    stage_load<kRecFwd>(rec_of(0), tid, stg);
-    stage_store<kRecFwd>(cbuf, tid, stg);
+    auto dma_rec = [&](int slot, int s) __attribute__((always_inline)) {
+        constexpr int PPR = kRecFwdPad / 256;             // 1-KB pieces per record
+        const float* rec = a.coef + ((size_t)s * a.C + c) * kRecStride + kG_Inv;
+        for (int p = wave; p < PPR; p += kWaves) {
+            const int f = p * 64 + lane;                  // 16-byte index inside the record
+            if (f < kRecFwd / 4) lds_dma16(rec + 4 * f, cbuf + (size_t)slot * kRecFwdPad + p * 256);
+        }
+    };
+    dma_rec(0, 0);
+    dma_wait_all();
     __syncthreads();
     if (lag) {                                            // interval 0 of the upper waves: staging only
-        stage_load<kRecFwd>(rec_of(a.S > 1 ? 1 : 0), tid, stg);
-        stage_store<kRecFwd>(cbuf + kRecFwd, tid, stg);
+        dma_rec(1, a.S > 1 ? 1 : 0);
+        dma_wait_all();
         __syncthreads();
     }
 
@@ -503,8 +510,10 @@ __global__ __launch_bounds__(kThreads) void adi_fwd_kernel(SweepArgs a) {
             int sp = s + lag + 1;                         // sweep of the item staged in this interval
             if (sp >= a.S) sp -= a.S;
             if (sp >= a.S) sp -= a.S;
-            stage_load<kRecFwd>(rec_of(sp), tid, stg);
-            const float* rec = cbuf + cur * kRecFwd;
+            int ps = cur + lag + 1;
+            if (ps >= kRing) ps -= kRing;
+            dma_rec(ps, sp);
+            const float* rec = cbuf + cur * kRecFwdPad;
             const int axs = (AX >= 0) ? AX : tab->axis[s];
             if (axs == PDE_AXIS_Y) relayout_all<N, J>(v, T, l, hf);
             solve_fwd<M, J>(v, rec, l, hf);
@@ -513,9 +522,7 @@ __global__ __launch_bounds__(kThreads) void adi_fwd_kernel(SweepArgs a) {
                 float* slot = a.ckpt + (size_t)ck_slot(a.ck, s) * a.B * a.C * plane;
                 store_planes<N, J, float>(slot, q, wave, lane, l, hf, a.B, a.C, c, T, v);
             }
-            int ps = cur + lag + 1;
-            if (ps >= kRing) ps -= kRing;
-            stage_store<kRecFwd>(cbuf + ps * kRecFwd, tid, stg);
+            dma_wait_all();                               // my pieces of the next record have landed
             __syncthreads();
             cur = (cur == kRing - 1) ? 0 : cur + 1;
         };

@@ -37,6 +37,7 @@ constexpr int kG_MaskX = 4 * kImage + 32;
 constexpr int kRecStride = 5 * kImage + 32;          // record stride in global memory (floats)
 // forward view (staged from kG_Inv)
 constexpr int kRecFwd = 2 * kImage + 32;
+constexpr int kRecFwdPad = ((kRecFwd / 4 + 63) / 64) * 256;   // LDS slot: whole 1-KB LDS-DMA pieces
 constexpr int kF_Inv = 0, kF_Jn = kImage, kF_E = kImage + 32;
 // backward view (staged from kG_Jn)
 constexpr int kBwdOff = kG_Jn;
