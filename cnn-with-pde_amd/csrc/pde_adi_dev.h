@@ -136,7 +136,9 @@ constexpr int kDppWaveShr1 = 0x138;   // lane i <- lane i-1
 #endif
 #if PDE_PACK
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ v2f v2_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v4f v4_fma(v4f a, v4f b, v4f c) { return __builtin_elementwise_fma(a, b, c); }
 #else
 // comparison build (make PACK=0): the same code on two scalar registers per pair
 struct v2f { float x, y; };
@@ -145,24 +147,40 @@ __device__ __forceinline__ v2f operator-(v2f a, v2f b) { return v2f{a.x - b.x, a
 __device__ __forceinline__ v2f operator*(v2f a, v2f b) { return v2f{a.x * b.x, a.y * b.y}; }
 __device__ __forceinline__ v2f operator-(v2f a) { return v2f{-a.x, -a.y}; }
 __device__ __forceinline__ v2f v2_fma(v2f a, v2f b, v2f c) { return v2f{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
+struct v4f { float x, y, z, w; };
+__device__ __forceinline__ v4f operator+(v4f a, v4f b) { return v4f{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+__device__ __forceinline__ v4f operator-(v4f a, v4f b) { return v4f{a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; }
+__device__ __forceinline__ v4f operator*(v4f a, v4f b) { return v4f{a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w}; }
+__device__ __forceinline__ v4f operator-(v4f a) { return v4f{-a.x, -a.y, -a.z, -a.w}; }
+__device__ __forceinline__ v4f v4_fma(v4f a, v4f b, v4f c) {
+    return v4f{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w)};
+}
 #endif
 template <int J> struct Pack;
 template <> struct Pack<1> { using P = float; };
 template <> struct Pack<2> { using P = v2f; };
+template <> struct Pack<4> { using P = v4f; };        // forward only: four planes share every coefficient read
 template <int C> __device__ __forceinline__ float pk_get(float p) { return p; }
 template <int C> __device__ __forceinline__ float pk_get(v2f p) { return C ? p.y : p.x; }
+template <int C> __device__ __forceinline__ float pk_get(v4f p) { return C == 0 ? p.x : C == 1 ? p.y : C == 2 ? p.z : p.w; }
 template <int C> __device__ __forceinline__ void pk_set(float& p, float v) { p = v; }
 template <int C> __device__ __forceinline__ void pk_set(v2f& p, float v) { if (C) p.y = v; else p.x = v; }
+template <int C> __device__ __forceinline__ void pk_set(v4f& p, float v) {
+    if (C == 0) p.x = v; else if (C == 1) p.y = v; else if (C == 2) p.z = v; else p.w = v;
+}
 __device__ __forceinline__ float pk_fma(float a, float b, float c) { return fmaf(a, b, c); }
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return v2_fma(a, b, c); }
+__device__ __forceinline__ v4f pk_fma(v4f a, v4f b, v4f c) { return v4_fma(a, b, c); }
 template <class P> __device__ __forceinline__ P pk_bc(float s);
 template <> __device__ __forceinline__ float pk_bc<float>(float s) { return s; }
 template <> __device__ __forceinline__ v2f pk_bc<v2f>(float s) { return v2f{s, s}; }
+template <> __device__ __forceinline__ v4f pk_bc<v4f>(float s) { return v4f{s, s, s, s}; }
 __device__ __forceinline__ float pk_hsum(float p) { return p; }
 __device__ __forceinline__ float pk_hsum(v2f p) { return p.x + p.y; }
 // per-component map (cross-lane moves have no packed form)
 template <class F> __device__ __forceinline__ float pk_map(float p, F&& f) { return f(p); }
 template <class F> __device__ __forceinline__ v2f pk_map(v2f p, F&& f) { return v2f{f(p.x), f(p.y)}; }
+template <class F> __device__ __forceinline__ v4f pk_map(v4f p, F&& f) { return v4f{f(p.x), f(p.y), f(p.z), f(p.w)}; }
 
 // Stage COUNT floats of a coefficient record global -> registers -> LDS: up to three 16-byte
 // pieces per thread, held in plain locals of the kernel (a struct here ends up in scratch).
@@ -504,7 +522,8 @@ __global__ __launch_bounds__(kThreads) void adi_fwd_kernel(SweepArgs a) {
 
     for (int q = g; q < nchunk; q += a.G) {
         typename Pack<J>::P v[M];
-        load_planes<N, J, IO>(u, q, wave, lane, l, hf, a.B, a.C, c, T, v);
+        if constexpr (J > 2) load_planes_seq<N, J, IO>(u, q, wave, lane, l, hf, a.B, a.C, c, T, v);   // 16, not 16*J, registers in flight
+        else load_planes<N, J, IO>(u, q, wave, lane, l, hf, a.B, a.C, c, T, v);
         auto sweep = [&](auto AXC, int s) {
             constexpr int AX = decltype(AXC)::value;
             int sp = s + lag + 1;                         // sweep of the item staged in this interval

@@ -7,7 +7,7 @@
 namespace pde {
 struct SweepArgsOpaque;          // = SweepArgs of pde_adi_dev.h, passed by pointer across units
 
-constexpr int kJFwd = 2;         // planes per lane in the forward kernel
+constexpr int kJFwd = 4;         // planes per lane in the forward kernel
 constexpr int kJBwd = 2;         // planes per lane in the backward kernel
 
 // return 0 on success, PDE_E_LAUNCH otherwise
