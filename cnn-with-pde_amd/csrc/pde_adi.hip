@@ -32,12 +32,12 @@
 //     y-direction second difference is taken across lanes with DPP), only the adjoint
 //     is re-laid out.  Parameter gradients are accumulated over the batch in registers
 //     and reduced deterministically (no float atomics).
-//   * what bounds the kernels (profiles/README.md): VALU issue.  A wave64 fp32 VALU
-//     instruction occupies its SIMD for 4 cycles, v_pk_*_f32 for 8 (same FLOP rate;
-//     tools/ubench), and the recurrences need ~10 (forward) / ~26 (backward) of them per
-//     element and time step, far more than the 8 / 12 bytes per element the tensors
-//     cost in HBM.  The two planes of a lane are written as a pair (Pack<2>) so that the
-//     packed form stays one flag away (make PACK=1); it measured 4 % slower.
+//   * what bounds the kernels (profiles/README.md): the SIMD's register-file port.  A
+//     wave64 fp32 VALU instruction holds its SIMD for 4 cycles (v_pk_*_f32: 8), and so does every dword
+//     an LDS read returns or an LDS write takes; cycles per wave ~ 4 x (VALU + LDS dwords) predicts both
+//     kernels within 10 %.  Hence: records arrive by LDS-DMA (no register round trip), the forward keeps
+//     FOUR planes per lane so that each coefficient read serves four planes, and the planes of a lane are
+//     written as one value (Pack<J>) so that the packed form stays one flag away (make PACK=1: 4 % slower).
 #include "pde_adi_dev.h"
 #include "pde_adi_launch.h"
 
