@@ -92,6 +92,12 @@ __device__ __forceinline__ void lds_dma16(const float* gsrc, float* lds_wave_bas
     const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)lds_wave_base);
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds), "v"(gsrc) : "memory");
 }
+// The same with a wave-uniform base address (SGPR pair) and a per-lane byte offset that never changes
+// (16*lane): no vector address arithmetic per piece.
+__device__ __forceinline__ void lds_dma16_s(const float* sbase, unsigned voff, float* lds_wave_base) {
+    const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(voff), "s"(sbase) : "memory");
+}
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 #ifdef PDE_STAMP
@@ -508,7 +514,7 @@ __global__ __launch_bounds__(kThreads) void adi_fwd_kernel(SweepArgs a) {
         const float* rec = a.coef + ((size_t)s * a.C + c) * kRecStride + kG_Inv;
         for (int p = wave; p < PPR; p += kWaves) {
             const int f = p * 64 + lane;                  // 16-byte index inside the record
-            if (f < kRecFwd / 4) lds_dma16(rec + 4 * f, cbuf + (size_t)slot * kRecFwdPad + p * 256);
+            if (f < kRecFwd / 4) lds_dma16_s(rec + p * 256, 16u * lane, cbuf + (size_t)slot * kRecFwdPad + p * 256);
         }
     };
     dma_rec(0, 0);
@@ -733,9 +739,9 @@ __device__ __forceinline__ void adi_bwd_body(const SweepArgs& a, int blk) {
         constexpr int PPR = RECP / 256;                   // 1-KB pieces per record
         for (int p = wave; p < PPR; p += kWaves) {
             const int f = p * 64 + lane;                  // 16-byte index inside the record
-            const float* src = a.coef + ((size_t)s * a.C + c) * kRecStride + kBwdOff + 4 * f;
+            const float* src = a.coef + ((size_t)s * a.C + c) * kRecStride + kBwdOff + p * 256;   // wave-uniform
             float* dst = cbuf + (size_t)slot * RECP + p * 256;                       // wave-uniform
-            if (f < REC / 4) lds_dma16(src, dst);
+            if (f < REC / 4) lds_dma16_s(src, 16u * lane, dst);
         }
     };
 
