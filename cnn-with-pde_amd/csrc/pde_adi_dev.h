@@ -138,7 +138,7 @@ constexpr int kDppWaveShr1 = 0x138;   // lane i <- lane i-1
 // coefficients, so they live in one 64-bit register pair (.x = plane 0, .y = plane 1) and every
 // recurrence step is one packed instruction; the coefficient is broadcast by op_sel, not copied.
 #ifndef PDE_PACK
-#define PDE_PACK 1
+#define PDE_PACK 0             // the Makefile's default; 1: v_pk_*_f32 (measured slower)
 #endif
 #if PDE_PACK
 typedef float v2f __attribute__((ext_vector_type(2)));
