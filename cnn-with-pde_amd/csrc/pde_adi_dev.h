@@ -131,12 +131,13 @@ __device__ __forceinline__ float dpp_move(float v) {
 constexpr int kDppWaveShl1 = 0x130;   // lane i <- lane i+1
 constexpr int kDppWaveShr1 = 0x138;   // lane i <- lane i-1
 
-// ---- the J planes of a lane as one packed value -----------------------------------------------
-// A wave64 fp32 VALU instruction issues in 4 cycles on gfx950 (16 lanes per cycle per SIMD;
-// tools/ubench/pk_bench.hip), and v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 do TWO fp32 per lane in
-// the same 4 cycles.  The two planes a lane works on go through identical arithmetic with shared
-// coefficients, so they live in one 64-bit register pair (.x = plane 0, .y = plane 1) and every
-// recurrence step is one packed instruction; the coefficient is broadcast by op_sel, not copied.
+// ---- the J planes of a lane as one value ------------------------------------------------------
+// The planes a lane works on (backward 2, forward 4) go through identical arithmetic with shared
+// coefficients, so they are written as ONE value of type Pack<J>::P: with PDE_PACK=0 (default) a struct
+// of scalars, i.e. J independent instruction chains; with PDE_PACK=1 an ext-vector, i.e. v_pk_fma_f32 /
+// v_pk_mul_f32 / v_pk_add_f32 with the coefficient broadcast by op_sel.  On gfx950 a wave64 fp32 VALU
+// instruction holds its SIMD for 4 cycles and a packed one for 8 (tools/ubench/pk_bench.hip), so the
+// packed build issues 22 % fewer instructions and is 4 % slower; it is kept as a build option only.
 #ifndef PDE_PACK
 #define PDE_PACK 0             // the Makefile's default; 1: v_pk_*_f32 (measured slower)
 #endif
