@@ -787,6 +787,97 @@ int pde_adi_param_grads(const PdeAdiDesc* d, int32_t sweeps_per_step, const floa
                         g_beta_slope, varying, static_cast<const float*>(workspace), G, static_cast<hipStream_t>(stream));
 }
 
+// ---- the whole layer call with a channel operator between the steps, looped on the host in C++ ----------
+// (one call from the binding instead of two per step: at the reference's own sizes, C = 3 and batch 128, the
+// layer is bound by the host's launch rate, and every Python -> ctypes transition costs as much as a launch)
+static size_t state_bytes(const PdeAdiDesc* d) {
+    return (size_t)d->B * d->C * d->N * d->N * (d->io_dtype == PDE_IO_BF16 ? 2 : 4);
+}
+
+int pde_adi_mixed_forward(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t mode, const void* u, void* states,
+                          const float* M, const float* alpha_base, const float* beta_base, const float* alpha_slope,
+                          const float* beta_slope, float* kappa_max, void* steps_workspace, size_t workspace_bytes,
+                          void* stream) {
+    if (!u || !states || !M || (mode != 1 && mode != 2)) return PDE_E_BADARG;
+    int rc = pde_adi_factor_steps(d, sweeps_per_step, alpha_base, beta_base, alpha_slope, beta_slope, kappa_max,
+                                  steps_workspace, workspace_bytes, stream);
+    if (rc != PDE_OK) return rc;
+    const int K = d->num_sweeps / sweeps_per_step, HW = d->N * d->N;
+    const size_t sb = state_bytes(d);
+    char* st = static_cast<char*>(states);
+    const void* cur = u;
+    for (int k = 0; k < K; ++k) {
+        void* a_k = st + (size_t)(2 * k) * sb;
+        void* b_k = st + (size_t)(2 * k + 1) * sb;
+        if (mode == 1) {                                   // cifar10.py:91: u <- M u, then the step's sweeps
+            rc = pde_channel_mix_forward(d->B, d->C, HW, d->io_dtype, cur, M, a_k, stream);
+            if (rc == PDE_OK) rc = pde_adi_forward_step(d, sweeps_per_step, k, a_k, b_k, steps_workspace, stream);
+        } else {                                           // SVHN.py:60-71: the sweeps, then u <- K u
+            rc = pde_adi_forward_step(d, sweeps_per_step, k, cur, a_k, steps_workspace, stream);
+            if (rc == PDE_OK) rc = pde_channel_mix_forward(d->B, d->C, HW, d->io_dtype, a_k, M, b_k, stream);
+        }
+        if (rc != PDE_OK) return rc;
+        cur = b_k;
+    }
+    return PDE_OK;
+}
+
+size_t pde_adi_mixed_backward_workspace_bytes(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t num_checkpoints) {
+    const size_t a = pde_adi_backward_step_workspace_bytes(d, sweeps_per_step, num_checkpoints);
+    if (a == 0) return 0;
+    return align_up(a, 256) + align_up(pde_channel_mix_backward_workspace_bytes(d->B, d->C, d->N * d->N), 256) +
+           2 * align_up(state_bytes(d), 256);
+}
+
+int pde_adi_mixed_backward(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t mode, const void* gy, const void* u,
+                           const void* states, const float* M, const uint64_t ckpt_mask[2], void* gu,
+                           const float* alpha_base, const float* beta_base, const float* alpha_slope,
+                           const float* beta_slope, float* g_alpha_base, float* g_beta_base, float* g_alpha_slope,
+                           float* g_beta_slope, float* gM, const void* steps_workspace, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+    if (!gy || !u || !states || !M || !gu || !gM || !workspace || (mode != 1 && mode != 2)) return PDE_E_BADARG;
+    const int nck = count_ckpt(ckpt_mask);
+    const size_t need = pde_adi_mixed_backward_workspace_bytes(d, sweeps_per_step, nck);
+    if (need == 0) return PDE_E_BADARG;
+    if (workspace_bytes < need || ((uintptr_t)workspace & 15)) return PDE_E_WORKSPACE;
+    const int K = d->num_sweeps / sweeps_per_step, HW = d->N * d->N;
+    const size_t sb = state_bytes(d);
+    const size_t ws_a = align_up(pde_adi_backward_step_workspace_bytes(d, sweeps_per_step, nck), 256);
+    const size_t ws_m = align_up(pde_channel_mix_backward_workspace_bytes(d->B, d->C, HW), 256);
+    char* w = static_cast<char*>(workspace);
+    void* aws = w;
+    void* mws = w + ws_a;
+    void* buf[2] = {w + ws_a + ws_m, w + ws_a + ws_m + align_up(sb, 256)};
+    const char* st = static_cast<const char*>(states);
+    const void* g_in = gy;                                 // gradient entering the step (never written)
+    int rc = PDE_OK;
+    for (int k = K - 1; k >= 0; --k) {
+        const int first = (k == K - 1), last = (k == 0);
+        const void* a_k = st + (size_t)(2 * k) * sb;
+        const void* b_k = st + (size_t)(2 * k + 1) * sb;
+        const void* prev = (k == 0) ? u : st + (size_t)(2 * k - 1) * sb;
+        void* g_mid = (g_in == buf[0]) ? buf[1] : buf[0];
+        void* g_out = last ? gu : ((g_mid == buf[0]) ? buf[1] : buf[0]);
+        if (mode == 1) {                                   // step = mix (prev -> a_k), sweeps (a_k -> b_k)
+            rc = pde_adi_backward_step(d, sweeps_per_step, k, g_in, b_k, nck ? a_k : nullptr, ckpt_mask, g_mid,
+                                       steps_workspace, aws, ws_a, first ? 0 : 1, stream);
+            if (rc == PDE_OK)
+                rc = pde_channel_mix_backward_steps(d->B, d->C, HW, d->io_dtype, prev, g_mid, M, g_out, gM, mws, ws_m,
+                                                    first ? 0 : 1, last ? 1 : 0, stream);
+        } else {                                           // step = sweeps (prev -> a_k), mix (a_k -> b_k)
+            rc = pde_channel_mix_backward_steps(d->B, d->C, HW, d->io_dtype, a_k, g_in, M, g_mid, gM, mws, ws_m,
+                                                first ? 0 : 1, last ? 1 : 0, stream);
+            if (rc == PDE_OK)
+                rc = pde_adi_backward_step(d, sweeps_per_step, k, g_mid, a_k, nck ? prev : nullptr, ckpt_mask, g_out,
+                                           steps_workspace, aws, ws_a, first ? 0 : 1, stream);
+        }
+        if (rc != PDE_OK) return rc;
+        g_in = g_out;
+    }
+    return pde_adi_param_grads(d, sweeps_per_step, alpha_base, beta_base, alpha_slope, beta_slope, g_alpha_base,
+                               g_beta_base, g_alpha_slope, g_beta_slope, steps_workspace, aws, stream);
+}
+
 int pde_adi_kappa_max(const PdeAdiDesc* d, const float* alpha_base, const float* beta_base, const float* alpha_slope,
                       const float* beta_slope, float* kappa_max, void* stream) {
     int rc = check_desc(d);

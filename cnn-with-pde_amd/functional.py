@@ -232,25 +232,10 @@ class _AdiMixedFn(torch.autograd.Function):
         kdev = torch.empty(len(sweeps), dtype=torch.float32, device=u.device) if want_kmax else None
         # states[k][0]: output of the step's first operator, states[k][1]: of its second (= input of step k+1)
         states = torch.empty((K, 2) + tuple(u.shape), dtype=u.dtype, device=u.device)
-        HW = N * N
         with torch.cuda.device(u.device):
-            st = _stream()
-            L.check(lib.pde_adi_factor_steps(C.byref(d), sps, *[_ptr(t) for t in p], _ptr(kdev), _ptr(sws),
-                                             sws.numel(), st), "pde_adi_factor_steps")
-            cur = u
-            for k in range(K):
-                a_k, b_k = states[k, 0], states[k, 1]
-                if mode == "pre":
-                    L.check(lib.pde_channel_mix_forward(B, Cc, HW, _io_dtype(u), _ptr(cur), _ptr(Mf), _ptr(a_k), st),
-                            "pde_channel_mix_forward")
-                    L.check(lib.pde_adi_forward_step(C.byref(d), sps, k, _ptr(a_k), _ptr(b_k), _ptr(sws), st),
-                            "pde_adi_forward_step")
-                else:
-                    L.check(lib.pde_adi_forward_step(C.byref(d), sps, k, _ptr(cur), _ptr(a_k), _ptr(sws), st),
-                            "pde_adi_forward_step")
-                    L.check(lib.pde_channel_mix_forward(B, Cc, HW, _io_dtype(u), _ptr(a_k), _ptr(Mf), _ptr(b_k), st),
-                            "pde_channel_mix_forward")
-                cur = b_k
+            L.check(lib.pde_adi_mixed_forward(C.byref(d), sps, 1 if mode == "pre" else 2, _ptr(u), _ptr(states), _ptr(Mf),
+                                              *[_ptr(t) for t in p], _ptr(kdev), _ptr(sws), sws.numel(), _stream()),
+                    "pde_adi_mixed_forward")
             ctx.kmax_host = ctx.kmax_event = None
             if want_kmax:
                 host = torch.empty(len(sweeps), dtype=torch.float32, pin_memory=True)
@@ -288,42 +273,16 @@ class _AdiMixedFn(torch.autograd.Function):
             bits = int(ckpt)
         nck = bin(bits).count("1")
         mask = (C.c_uint64 * 2)(bits & (2 ** 64 - 1), bits >> 64)
-        ws = _workspace(lib.pde_adi_backward_step_workspace_bytes(C.byref(d), sps, nck), u.device)
-        mws = _workspace(lib.pde_channel_mix_backward_workspace_bytes(B, Cc, HW), u.device)
-        g_in = gy.to(u.dtype).contiguous()               # read only: it may be autograd's own buffer
-        bufs = [torch.empty_like(g_in), torch.empty_like(g_in)]
-
-        def other(cur):                                  # a scratch buffer that is not `cur`
-            return bufs[1] if cur is bufs[0] else bufs[0]
-        g_a = g_in
+        ws = _workspace(lib.pde_adi_mixed_backward_workspace_bytes(C.byref(d), sps, nck), u.device)
+        g_in = gy.to(u.dtype).contiguous()
+        g_a = torch.empty_like(g_in)
         gp = [torch.empty_like(t) for t in p]
         gM = torch.empty_like(Mf)
-        io = _io_dtype(u)
         with torch.cuda.device(u.device):
-            st = _stream()
-            for k in range(K - 1, -1, -1):
-                first, last = (k == K - 1), (k == 0)
-                a_k, b_k = states[k, 0], states[k, 1]
-                prev = u if k == 0 else states[k - 1, 1]
-                g_b = other(g_a)
-                g_c = other(g_b)                         # never g_in: that one is only ever read
-                if mode == "pre":                        # step = mix (prev -> a_k), sweeps (a_k -> b_k)
-                    L.check(lib.pde_adi_backward_step(C.byref(d), sps, k, _ptr(g_a), _ptr(b_k), _ptr(a_k if nck else None),
-                                                      mask, _ptr(g_b), _ptr(ctx.sws), _ptr(ws), ws.numel(), 0 if first else 1,
-                                                      st), "pde_adi_backward_step")
-                    L.check(lib.pde_channel_mix_backward_steps(B, Cc, HW, io, _ptr(prev), _ptr(g_b), _ptr(Mf), _ptr(g_c),
-                                                               _ptr(gM), _ptr(mws), mws.numel(), 0 if first else 1,
-                                                               1 if last else 0, st), "pde_channel_mix_backward_steps")
-                else:                                    # step = sweeps (prev -> a_k), mix (a_k -> b_k)
-                    L.check(lib.pde_channel_mix_backward_steps(B, Cc, HW, io, _ptr(a_k), _ptr(g_a), _ptr(Mf), _ptr(g_b),
-                                                               _ptr(gM), _ptr(mws), mws.numel(), 0 if first else 1,
-                                                               1 if last else 0, st), "pde_channel_mix_backward_steps")
-                    L.check(lib.pde_adi_backward_step(C.byref(d), sps, k, _ptr(g_b), _ptr(a_k), _ptr(prev if nck else None),
-                                                      mask, _ptr(g_c), _ptr(ctx.sws), _ptr(ws), ws.numel(), 0 if first else 1,
-                                                      st), "pde_adi_backward_step")
-                g_a = g_c
-            L.check(lib.pde_adi_param_grads(C.byref(d), sps, *[_ptr(t) for t in p], *[_ptr(t) for t in gp], _ptr(ctx.sws),
-                                            _ptr(ws), st), "pde_adi_param_grads")
+            L.check(lib.pde_adi_mixed_backward(C.byref(d), sps, 1 if mode == "pre" else 2, _ptr(g_in), _ptr(u), _ptr(states),
+                                               _ptr(Mf), mask, _ptr(g_a), *[_ptr(t) for t in p], *[_ptr(t) for t in gp],
+                                               _ptr(gM), _ptr(ctx.sws), _ptr(ws), ws.numel(), _stream()),
+                    "pde_adi_mixed_backward")
         ctx.sws = None
         gp = [g.reshape(s) for g, s in zip(gp, ctx.param_shapes)]
         return (g_a, *gp, gM.to(ctx.M_dtype), None, None, None, None, None, None, None)

@@ -139,6 +139,26 @@ int pde_adi_param_grads(const PdeAdiDesc* d, int32_t sweeps_per_step,
                         float* g_alpha_base, float* g_beta_base, float* g_alpha_slope, float* g_beta_slope,
                         const void* steps_workspace, const void* workspace, void* stream);
 
+/* The same sequence looped on the host inside the library: ONE call per layer forward / backward.
+ * mode 1: u <- M u before every step (cifar10.py:91, cifar_2version.py:86); 2: after every step
+ * (SVHN.py:71).  `states`: K*2 tensors of u's shape and type, K = num_sweeps / sweeps_per_step —
+ * states[2k] the output of step k's first operator, states[2k+1] of its second; the layer output is
+ * states[2K-1].  The backward needs them intact, and `u`.  ckpt_mask is relative to a step. */
+int pde_adi_mixed_forward(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t mode,
+                          const void* u, void* states, const float* M,
+                          const float* alpha_base, const float* beta_base,
+                          const float* alpha_slope, const float* beta_slope,
+                          float* kappa_max, void* steps_workspace, size_t workspace_bytes, void* stream);
+size_t pde_adi_mixed_backward_workspace_bytes(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t num_checkpoints);
+int pde_adi_mixed_backward(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t mode,
+                           const void* gy, const void* u, const void* states, const float* M,
+                           const uint64_t ckpt_mask[2], void* gu,
+                           const float* alpha_base, const float* beta_base,
+                           const float* alpha_slope, const float* beta_slope,
+                           float* g_alpha_base, float* g_beta_base, float* g_alpha_slope, float* g_beta_slope,
+                           float* gM, const void* steps_workspace,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- channel operators ------------------------------------------ */
 
 /* out[b,i,p] = sum_j M[i,j] u[b,j,p]  — cifar10.py:65-72 apply_channel_mixing and
