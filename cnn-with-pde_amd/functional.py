@@ -69,7 +69,22 @@ def _io_dtype(t: torch.Tensor) -> int:
     raise L.PdeError(f"unsupported tensor dtype {t.dtype} (float32 or bfloat16)")
 
 
+_desc_cache = {}
+
+
 def _make_desc(B, Cc, N, io, sweeps: Sequence[Sweep], smooth3, clamp_max, eps) -> L.PdeAdiDesc:
+    """The launch descriptor (read-only for the library).  Cached: filling ~100 ctypes fields costs more
+    host time than the kernels of a small layer take on the device."""
+    key = (B, Cc, N, io, tuple(sweeps), bool(smooth3), clamp_max, float(eps))
+    d = _desc_cache.get(key)
+    if d is None:
+        if len(_desc_cache) > 256:
+            _desc_cache.clear()
+        d = _desc_cache[key] = _build_desc(B, Cc, N, io, sweeps, smooth3, clamp_max, eps)
+    return d
+
+
+def _build_desc(B, Cc, N, io, sweeps: Sequence[Sweep], smooth3, clamp_max, eps) -> L.PdeAdiDesc:
     if len(sweeps) > L.PDE_MAX_SWEEPS:
         raise L.PdeError(f"{len(sweeps)} sweeps in one launch exceed PDE_MAX_SWEEPS={L.PDE_MAX_SWEEPS}")
     d = L.PdeAdiDesc()

@@ -36,8 +36,15 @@ class _AdiBase(nn.Module):
     _clamp_max = None
 
     def _schedule(self):
+        """Per-step sweep lists; cached per (dt, dx, dy, steps) — the attributes may be changed from outside."""
         dy = getattr(self, "dy", self.dx)
-        return F_.adi_schedule(self.dt, self.dx, dy, self.num_steps, self._split)
+        key = (self.dt, self.dx, dy, self.num_steps, self._split)
+        cache = self.__dict__.setdefault("_schedule_cache", {})
+        steps = cache.get(key)
+        if steps is None:
+            cache.clear()
+            steps = cache[key] = tuple(tuple(st) for st in F_.adi_schedule(self.dt, self.dx, dy, self.num_steps, self._split))
+        return steps
 
     def get_alpha_beta_at_time(self, t):
         """clamp(base + slope*t) — mnist_test.py:33-42 / cifar10.py:53-63 (host-side helper)."""
