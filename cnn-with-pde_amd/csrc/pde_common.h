@@ -48,6 +48,13 @@ constexpr int kB_Jn = 0, kB_E = 32, kB_Inv = kImage + 32, kB_KapX = 2 * kImage +
 // position of global index j inside a line image row
 __host__ __device__ inline int half_pos(int j, int N) { return (j < N / 2) ? j : kHalfPad + (N - 1 - j); }
 
+// bf16 tensors through the bf16 MFMA (pde_mix_bf16.hip); C = 64 / 128, HW a multiple of 64
+bool mix_bf16_ok(int C, int HW);
+int mix_bf16_splits(int B, int C, int HW);
+int mix_bf16_apply(int B, int C, int HW, const void* u, const float* M, void* out, int trans, hipStream_t st);
+int mix_bf16_backward(int B, int C, int HW, const void* u, const void* g, const float* M, void* gu, float* part, int nsplit,
+                      int accp, hipStream_t st);
+
 struct Timing {
     bool on = false;
     double fwd_ms = 0, bwd_ms = 0;

@@ -495,6 +495,7 @@ int pde_channel_mix_forward(int32_t B, int32_t C, int32_t HW, int32_t io_dtype, 
     if (B <= 0 || C <= 0 || HW <= 0 || !u || !M || !out) return PDE_E_BADARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (io_dtype != PDE_IO_F32 && io_dtype != PDE_IO_BF16) return PDE_E_BADARG;
+    if (io_dtype == PDE_IO_BF16 && mix_bf16_ok(C, HW)) return mix_bf16_apply(B, C, HW, u, M, out, 0, st);
     if (mfma_apply_ok(C, HW)) return launch_apply_mfma(B, C, HW, io_dtype, u, M, out, 0, st);
     dim3 grid((HW + 255) / 256, B);
     if (io_dtype == PDE_IO_F32)
@@ -528,6 +529,13 @@ int pde_channel_mix_backward_steps(int32_t B, int32_t C, int32_t HW, int32_t io_
     dim3 grid((HW + 255) / 256, B);
     const int tiles = (C + kT - 1) / kT;
     float* part = static_cast<float*>(workspace);
+    if (io_dtype == PDE_IO_BF16 && mix_bf16_ok(C, HW)) {   // exact bf16 products on the bf16 MFMA
+        const int nsplit = mix_bf16_splits(B, C, HW);
+        const int rc = mix_bf16_backward(B, C, HW, u, gout, M, gu, part, nsplit, accumulate, st);
+        if (rc != PDE_OK) return rc;
+        if (finalize) hipLaunchKernelGGL(mix_gm_reduce_kernel, dim3((C * C + 31) / 32), dim3(256), 0, st, part, gM, C * C, nsplit);
+        return check_launch();
+    }
     if (mfma_fused_ok(C, HW) && getenv("PDE_MIX_UNFUSED") == nullptr) {
         const int nsplit = fused_splits(B, C, HW);
         if (io_dtype == PDE_IO_F32) {

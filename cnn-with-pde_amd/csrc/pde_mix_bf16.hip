@@ -1,0 +1,269 @@
+// Channel operators on bf16 tensors (SVHN width C = 128, bf16 I/O).
+//
+// With bf16 inputs the products of the mixing are exact in a bf16 MFMA: v_mfma_f32_32x32x16_bf16 multiplies
+// bf16 x bf16 into fp32 and accumulates in fp32, at 16x the rate of the fp32 MFMA the generic path uses
+// (32 cycles for K = 16 against 64 cycles for K = 2).  Only the fp32 matrix M has to be split, M = hi + lo
+// with both parts bf16 (relative error 2^-17, far below the bf16 resolution of the outputs):
+//   forward      out^T tile = u^T (hi + lo)^T      2 MFMAs per K = 16
+//   backward     gu^T  tile = g^T (hi + lo)        2 MFMAs per K = 16
+//                gM   += g u^T over the pixels     1 MFMA  per K = 16, EXACT products
+// Operand maps (cdna_hip_programming.md §3): lane l = (h = l>>5, r = l&31) holds A[row r][k = 8h + j] and
+// B[k = 8h + j][col r], j = 0..7; D: col = r, row = (reg&3) + 8*(reg>>2) + 4*h.
+// A workgroup stages a [C channels][64 pixels] tile in LDS in its natural layout (rows of 128 B + 16 B pad):
+//   * k = pixel (gM): both operands are row reads, ds_read_b128;
+//   * k = channel (out, gu): the A operand u^T / g^T comes from the same image through the transposing read
+//     ds_read_b64_tr_b16 (4 channel rows x 16 pixels per 16 lanes, delivered pixel-major);
+//   * the result tile is [pixel][channel] on the lanes, i.e. every lane holds 4 x 4 consecutive pixels of ONE
+//     channel: it goes back through an LDS image and out as 16-byte stores.
+#include "pde_common.h"
+
+#include <cstdlib>
+
+namespace pde {
+namespace {
+
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef short v8s __attribute__((ext_vector_type(8)));
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kPx = 64;                 // pixels per tile
+constexpr int kRow = 144;               // bytes per tile row: 128 + 16 pad (16 consecutive rows hit 64 distinct banks)
+
+__device__ __forceinline__ unsigned short f2bf(float f) {      // round to nearest even, NaN kept
+    unsigned int u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned int)h << 16); }
+
+// hi/lo bf16 fragments of M for the B operand, in LDS: [piece][tile][k-step][lane][8].
+// TRANS = false (forward):  B[k = in j][col = out i]  = M[i][j]:  lane (h,r) of (ot,ks): M[32ot + r][16ks + 8h + jj]
+// TRANS = true  (backward): B[k = out i][col = in j]  = M[i][j]:  lane (h,r) of (jt,ks): M[16ks + 8h + jj][32jt + r]
+template <int C, bool TRANS>
+__device__ __forceinline__ void build_frags(const float* __restrict__ M, unsigned short* frag, int tid, int nthreads) {
+    constexpr int T = C / 32, KS = C / 16;
+    for (int e = tid; e < T * KS * 64; e += nthreads) {
+        const int lane = e & 63, ks = (e >> 6) % KS, t = (e >> 6) / KS;
+        const int h = lane >> 5, r = lane & 31;
+        unsigned short hi[8], lo[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const float w = TRANS ? M[(16 * ks + 8 * h + jj) * C + 32 * t + r] : M[(32 * t + r) * C + 16 * ks + 8 * h + jj];
+            hi[jj] = f2bf(w);
+            lo[jj] = f2bf(w - bf2f(hi[jj]));
+        }
+        uint4* dh = reinterpret_cast<uint4*>(frag + (size_t)e * 8);
+        uint4* dl = reinterpret_cast<uint4*>(frag + (size_t)(T * KS * 64 + e) * 8);
+        *dh = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
+        *dl = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
+    }
+}
+
+// global [C][HW] bf16 (one sample, pixels p0..p0+63) -> LDS image, 16-byte pieces
+template <int C>
+__device__ __forceinline__ void load_tile(const unsigned short* __restrict__ src, int HW, int p0, unsigned char* img,
+                                          int tid, int nthreads) {
+    for (int e = tid; e < C * 8; e += nthreads) {
+        const int row = e >> 3, ch = e & 7;
+        const uint4 v = *reinterpret_cast<const uint4*>(src + (size_t)row * HW + p0 + 8 * ch);
+        *reinterpret_cast<uint4*>(img + row * kRow + 16 * ch) = v;
+    }
+}
+template <int C>
+__device__ __forceinline__ void store_tile(unsigned short* __restrict__ dst, int HW, int p0, const unsigned char* img,
+                                           int tid, int nthreads) {
+    for (int e = tid; e < C * 8; e += nthreads) {
+        const int row = e >> 3, ch = e & 7;
+        *reinterpret_cast<uint4*>(dst + (size_t)row * HW + p0 + 8 * ch) = *reinterpret_cast<const uint4*>(img + row * kRow + 16 * ch);
+    }
+}
+
+// A operand X^T from the natural image of X ([channel][pixel]): A[row = pixel 32pg + r][k = channel 16ks + 8h + jj]
+__device__ __forceinline__ v8bf tr_operand(const unsigned char* img, int pg, int ks, int lane) {
+    const int grp = lane >> 4, i = lane & 15, h = lane >> 5;
+    const int q = i >> 2, p = i & 3;
+    // lane 4q+p of a 16-lane group supplies row q (of 4 channel rows), pixel columns 4p..4p+3 of the group's 16
+    const unsigned char* a0 = img + (16 * ks + 8 * h + q) * kRow + (32 * pg + 16 * (grp & 1) + 4 * p) * 2;
+    const v4s lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(a0));
+    const v4s hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(a0 + 4 * kRow));
+    const v8s all = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+    return __builtin_bit_cast(v8bf, all);
+}
+__device__ __forceinline__ v8bf frag_operand(const unsigned short* frag, int idx) {
+    return __builtin_bit_cast(v8bf, *reinterpret_cast<const v8s*>(frag + (size_t)idx * 8));
+}
+// row operand: 8 consecutive pixels of one channel row of the image
+__device__ __forceinline__ v8bf row_operand(const unsigned char* img, int row, int px) {
+    return __builtin_bit_cast(v8bf, *reinterpret_cast<const v8s*>(img + row * kRow + px * 2));
+}
+// D tile [pixel][channel]: lane (h,r) holds channel 32t + r, pixels 32pg + 8q + 4h + 0..3 in regs 4q..4q+3
+__device__ __forceinline__ void put_result(unsigned char* img, const f32x16& acc, int t, int pg, int lane) {
+    const int h = lane >> 5, r = lane & 31;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned int a = f2bf(acc[4 * q]) | ((unsigned int)f2bf(acc[4 * q + 1]) << 16);
+        const unsigned int b = f2bf(acc[4 * q + 2]) | ((unsigned int)f2bf(acc[4 * q + 3]) << 16);
+        *reinterpret_cast<uint2*>(img + (32 * t + r) * kRow + (32 * pg + 8 * q + 4 * h) * 2) = make_uint2(a, b);
+    }
+}
+
+// ---- forward: out = M u -------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(C * 4) void mix_apply_bf16_kernel(const unsigned short* __restrict__ u, const float* __restrict__ M,
+                                                               unsigned short* __restrict__ out, int B, int HW, int trans) {
+    constexpr int T = C / 32, KS = C / 16, NT = C * 4, FR = T * KS * 64;     // waves = 2 pixel groups x T channel tiles
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned short* frag = reinterpret_cast<unsigned short*>(smem);          // [2][FR][8] bf16 = 4*C*C bytes
+    unsigned char* img_in = smem + (size_t)4 * C * C;
+    unsigned char* img_out = img_in + C * kRow;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (trans) build_frags<C, true>(M, frag, tid, NT);
+    else build_frags<C, false>(M, frag, tid, NT);
+    const int pg = wave & 1, ot = wave >> 1;
+    const int per_sample = HW / kPx;
+    const long total = (long)B * per_sample;
+    for (long tile = blockIdx.x; tile < total; tile += gridDim.x) {
+        const int b = (int)(tile / per_sample), p0 = (int)(tile % per_sample) * kPx;
+        __syncthreads();                                   // fragments built / previous tile's images consumed
+        load_tile<C>(u + (size_t)b * C * HW, HW, p0, img_in, tid, NT);
+        __syncthreads();
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll 2
+        for (int ks = 0; ks < KS; ++ks) {
+            const v8bf a = tr_operand(img_in, pg, ks, lane);
+            const int fi = (ot * KS + ks) * 64 + lane;
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, frag_operand(frag, fi), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, frag_operand(frag, FR + fi), acc, 0, 0, 0);
+        }
+        put_result(img_out, acc, ot, pg, lane);
+        __syncthreads();
+        store_tile<C>(out + (size_t)b * C * HW, HW, p0, img_out, tid, NT);
+    }
+}
+
+// ---- backward: gu = M^T g and the partial sums of gM = g u^T ---------------------------------------------
+template <int C>
+__global__ __launch_bounds__(C * 4) void mix_bwd_bf16_kernel(const unsigned short* __restrict__ u, const unsigned short* __restrict__ g,
+                                                             const float* __restrict__ M, unsigned short* __restrict__ gu,
+                                                             float* __restrict__ part, int B, int HW, int accp) {
+    constexpr int T = C / 32, KS = C / 16, NT = C * 4, W = C / 16, FR = T * KS * 64;
+    constexpr int NTM = T * T / W;                         // gM tiles per wave (C = 64: 1, C = 128: 2)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned short* frag = reinterpret_cast<unsigned short*>(smem);
+    unsigned char* img_g = smem + (size_t)4 * C * C;
+    unsigned char* img_u = img_g + C * kRow;
+    unsigned char* img_o = img_u + C * kRow;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, r = lane & 31;
+    build_frags<C, true>(M, frag, tid, NT);
+    const int pg = wave & 1, jt = wave >> 1;               // my gu tile: pixel group, input-channel tile
+    f32x16 acc_m[NTM];
+#pragma unroll
+    for (int t = 0; t < NTM; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc_m[t][i] = 0.f;
+    const int per_sample = HW / kPx;
+    const long total = (long)B * per_sample;
+    for (long tile = blockIdx.x; tile < total; tile += gridDim.x) {
+        const int b = (int)(tile / per_sample), p0 = (int)(tile % per_sample) * kPx;
+        __syncthreads();
+        load_tile<C>(g + (size_t)b * C * HW, HW, p0, img_g, tid, NT);
+        load_tile<C>(u + (size_t)b * C * HW, HW, p0, img_u, tid, NT);
+        __syncthreads();
+        // gM: contraction over the 64 pixels of the tile, 16 per MFMA
+#pragma unroll
+        for (int kp = 0; kp < kPx / 16; ++kp) {
+#pragma unroll
+            for (int t = 0; t < NTM; ++t) {
+                const int tl = wave + W * t, it = tl / T, jt2 = tl % T;
+                const v8bf a = row_operand(img_g, 32 * it + r, 16 * kp + 8 * h);
+                const v8bf bb = row_operand(img_u, 32 * jt2 + r, 16 * kp + 8 * h);
+                acc_m[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bb, acc_m[t], 0, 0, 0);
+            }
+        }
+        // gu^T tile = g^T (hi + lo)
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll 2
+        for (int ks = 0; ks < KS; ++ks) {
+            const v8bf a = tr_operand(img_g, pg, ks, lane);
+            const int fi = (jt * KS + ks) * 64 + lane;
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, frag_operand(frag, fi), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, frag_operand(frag, FR + fi), acc, 0, 0, 0);
+        }
+        put_result(img_o, acc, jt, pg, lane);
+        __syncthreads();
+        store_tile<C>(gu + (size_t)b * C * HW, HW, p0, img_o, tid, NT);
+    }
+    float* dst = part + (size_t)blockIdx.x * C * C;
+#pragma unroll
+    for (int t = 0; t < NTM; ++t) {
+        const int tl = wave + W * t, it = tl / T, jt2 = tl % T;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int i = 32 * it + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            float* o = dst + i * C + 32 * jt2 + r;
+            *o = accp ? *o + acc_m[t][reg] : acc_m[t][reg];
+        }
+    }
+}
+
+inline void ensure_lds(const void* kernel, int bytes, unsigned long long& done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
+    if (!((done >> dev) & 1ull)) {
+        (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        done |= 1ull << dev;
+    }
+}
+
+template <int C>
+void launch_apply(const void* u, const float* M, void* out, int B, int HW, int trans, hipStream_t st) {
+    const size_t lds = (size_t)4 * C * C + 2 * (size_t)C * kRow;
+    static unsigned long long cfg = 0;
+    ensure_lds((const void*)mix_apply_bf16_kernel<C>, (int)lds, cfg);
+    const long tiles = (long)B * (HW / kPx);
+    const int per_cu = C == 64 ? 4 : 1;                    // workgroups an LDS footprint of 34 / 100 KB allows
+    const long grid = tiles < 256L * per_cu ? tiles : 256L * per_cu;
+    hipLaunchKernelGGL((mix_apply_bf16_kernel<C>), dim3((unsigned)grid), dim3(C * 4), lds, st, (const unsigned short*)u, M,
+                       (unsigned short*)out, B, HW, trans);
+}
+template <int C>
+void launch_bwd(const void* u, const void* g, const float* M, void* gu, float* part, int B, int HW, int nsplit, int accp,
+                hipStream_t st) {
+    const size_t lds = (size_t)4 * C * C + 3 * (size_t)C * kRow;
+    static unsigned long long cfg = 0;
+    ensure_lds((const void*)mix_bwd_bf16_kernel<C>, (int)lds, cfg);
+    hipLaunchKernelGGL((mix_bwd_bf16_kernel<C>), dim3((unsigned)nsplit), dim3(C * 4), lds, st, (const unsigned short*)u,
+                       (const unsigned short*)g, M, (unsigned short*)gu, part, B, HW, accp);
+}
+
+}  // namespace
+
+// entry points used by pde_mix.hip (same shared library)
+bool mix_bf16_ok(int C, int HW) {
+    return (C == 64 || C == 128) && (HW % kPx) == 0 && getenv("PDE_MIX_NO_BF16_MFMA") == nullptr;
+}
+int mix_bf16_splits(int B, int C, int HW) {
+    const long tiles = (long)B * (HW / kPx);
+    const long want = C == 64 ? 768 : 256;                 // resident workgroups (LDS 43 / 118 KB each)
+    return (int)(tiles < want ? tiles : want);
+}
+int mix_bf16_apply(int B, int C, int HW, const void* u, const float* M, void* out, int trans, hipStream_t st) {
+    if (C == 64) launch_apply<64>(u, M, out, B, HW, trans, st);
+    else launch_apply<128>(u, M, out, B, HW, trans, st);
+    return check_launch();
+}
+int mix_bf16_backward(int B, int C, int HW, const void* u, const void* g, const float* M, void* gu, float* part, int nsplit,
+                      int accp, hipStream_t st) {
+    if (C == 64) launch_bwd<64>(u, g, M, gu, part, B, HW, nsplit, accp, st);
+    else launch_bwd<128>(u, g, M, gu, part, B, HW, nsplit, accp, st);
+    return check_launch();
+}
+
+}  // namespace pde

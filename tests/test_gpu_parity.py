@@ -271,9 +271,10 @@ def test_channel_mix_bf16_io(C):
     u64, M64 = u.double().requires_grad_(True), M.double().requires_grad_(True)
     ref = torch.matmul(M64, u64)
     ref.backward(go.double())
-    assert G.rel_err(out.detach().float().cpu().view(B, C, HW), ref.detach()) <= 2e-2
-    assert G.rel_err(ud.grad.float().cpu().view(B, C, HW), u64.grad) <= 2e-2
-    assert G.rel_err(Md.grad.cpu(), M64.grad) <= 1e-4          # fp32 accumulation of bf16 inputs
+    assert G.rel_err(out.detach().float().cpu().view(B, C, HW), ref.detach()) <= 6e-3      # one bf16 rounding of the result
+    assert G.rel_err(ud.grad.float().cpu().view(B, C, HW), u64.grad) <= 6e-3
+    # C = 64 / 128 run on the bf16 MFMA: products of bf16 inputs are exact there, the sum is fp32
+    assert G.rel_err(Md.grad.cpu(), M64.grad) <= (2e-5 if C in (64, 128) else 1e-4)
 
 
 def test_explicit_layers_vs_oracle():
