@@ -71,6 +71,25 @@ __device__ __forceinline__ void load_tile(const unsigned short* __restrict__ src
         *reinterpret_cast<uint4*>(img + row * kRow + 16 * ch) = v;
     }
 }
+// The same in two halves, so that the NEXT tile's global loads are in flight while the current one is
+// being multiplied: fetch -> (compute of the previous tile) -> deposit.
+// (every thread owns exactly two 16-byte pieces of a tile: C*8 pieces, C*4 threads; plain variables, not an
+// array: an array passed down by reference ended up in scratch here)
+template <int C>
+__device__ __forceinline__ void fetch_tile(const unsigned short* __restrict__ src, int HW, int p0, uint4& t0, uint4& t1, int tid) {
+    constexpr int NT = C * 4;
+    const int e0 = tid, e1 = tid + NT;
+    t0 = *reinterpret_cast<const uint4*>(src + (size_t)(e0 >> 3) * HW + p0 + 8 * (e0 & 7));
+    t1 = *reinterpret_cast<const uint4*>(src + (size_t)(e1 >> 3) * HW + p0 + 8 * (e1 & 7));
+}
+template <int C>
+__device__ __forceinline__ void deposit_tile(const uint4& t0, const uint4& t1, unsigned char* img, int tid) {
+    constexpr int NT = C * 4;
+    const int e0 = tid, e1 = tid + NT;
+    *reinterpret_cast<uint4*>(img + (e0 >> 3) * kRow + 16 * (e0 & 7)) = t0;
+    *reinterpret_cast<uint4*>(img + (e1 >> 3) * kRow + 16 * (e1 & 7)) = t1;
+}
+
 template <int C>
 __device__ __forceinline__ void store_tile(unsigned short* __restrict__ dst, int HW, int p0, const unsigned char* img,
                                            int tid, int nthreads) {
@@ -124,11 +143,16 @@ __global__ __launch_bounds__(C * 4) void mix_apply_bf16_kernel(const unsigned sh
     const int pg = wave & 1, ot = wave >> 1;
     const int per_sample = HW / kPx;
     const long total = (long)B * per_sample;
+    uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0;
+    if ((long)blockIdx.x < total)
+        fetch_tile<C>(u + (size_t)(blockIdx.x / per_sample) * C * HW, HW, (int)(blockIdx.x % per_sample) * kPx, n0, n1, tid);
     for (long tile = blockIdx.x; tile < total; tile += gridDim.x) {
         const int b = (int)(tile / per_sample), p0 = (int)(tile % per_sample) * kPx;
         __syncthreads();                                   // fragments built / previous tile's images consumed
-        load_tile<C>(u + (size_t)b * C * HW, HW, p0, img_in, tid, NT);
+        deposit_tile<C>(n0, n1, img_in, tid);
         __syncthreads();
+        const long tn = tile + gridDim.x;                  // the next tile's loads fly during this tile's MFMAs
+        if (tn < total) fetch_tile<C>(u + (size_t)(tn / per_sample) * C * HW, HW, (int)(tn % per_sample) * kPx, n0, n1, tid);
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -168,12 +192,26 @@ __global__ __launch_bounds__(C * 4) void mix_bwd_bf16_kernel(const unsigned shor
         for (int i = 0; i < 16; ++i) acc_m[t][i] = 0.f;
     const int per_sample = HW / kPx;
     const long total = (long)B * per_sample;
+    uint4 g0 = make_uint4(0, 0, 0, 0), g1 = g0, u0 = g0, u1 = g0;
+    if ((long)blockIdx.x < total) {
+        const size_t o = (size_t)(blockIdx.x / per_sample) * C * HW;
+        const int q0 = (int)(blockIdx.x % per_sample) * kPx;
+        fetch_tile<C>(g + o, HW, q0, g0, g1, tid);
+        fetch_tile<C>(u + o, HW, q0, u0, u1, tid);
+    }
     for (long tile = blockIdx.x; tile < total; tile += gridDim.x) {
         const int b = (int)(tile / per_sample), p0 = (int)(tile % per_sample) * kPx;
         __syncthreads();
-        load_tile<C>(g + (size_t)b * C * HW, HW, p0, img_g, tid, NT);
-        load_tile<C>(u + (size_t)b * C * HW, HW, p0, img_u, tid, NT);
+        deposit_tile<C>(g0, g1, img_g, tid);
+        deposit_tile<C>(u0, u1, img_u, tid);
         __syncthreads();
+        const long tn = tile + gridDim.x;
+        if (tn < total) {
+            const size_t o = (size_t)(tn / per_sample) * C * HW;
+            const int q0 = (int)(tn % per_sample) * kPx;
+            fetch_tile<C>(g + o, HW, q0, g0, g1, tid);
+            fetch_tile<C>(u + o, HW, q0, u0, u1, tid);
+        }
         // gM: contraction over the 64 pixels of the tile, 16 per MFMA
 #pragma unroll
         for (int kp = 0; kp < kPx / 16; ++kp) {
