@@ -14,7 +14,7 @@ import torch
 
 from . import _lib as L
 
-__all__ = ["Sweep", "adi_schedule", "adi_diffuse", "adi_diffuse_mixed", "plan_checkpoints", "kappa_max_async", "channel_mix", "explicit5_step", "jacobi_diffuse",
+__all__ = ["Sweep", "adi_schedule", "adi_diffuse", "adi_diffuse_mixed", "plan_checkpoints", "kappa_max_async", "channel_mix", "skip_blend", "explicit5_step", "jacobi_diffuse",
            "timing_enable", "timing_read"]
 
 
@@ -472,6 +472,48 @@ def jacobi_diffuse(u, a_row, b_col, nt: int):
     if u.shape[0] == 0:
         return _empty_passthrough(u, a_row, b_col)
     return _JacobiFn.apply(u, a_row, b_col, int(nt))
+
+
+# --------------------------------------------------------------------------- SVHN skip connection
+class _SkipBlendFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u0, u, skip_weight):
+        lib = L.load()
+        _require_cuda(u0, u, skip_weight)
+        if u0.shape != u.shape:
+            raise L.PdeError(f"shapes differ: {tuple(u0.shape)} vs {tuple(u.shape)}")
+        dt = u.dtype if u.dtype in (torch.float32, torch.bfloat16) else torch.float32
+        a, b = u0.to(dt).contiguous(), u.to(dt).contiguous()
+        w = skip_weight.detach().to(torch.float32).reshape(1).contiguous()
+        out = torch.empty_like(b)
+        with torch.cuda.device(b.device):
+            L.check(lib.pde_skip_blend_forward(b.numel(), _io_dtype(b), _ptr(a), _ptr(b), _ptr(w), _ptr(out), _stream()),
+                    "pde_skip_blend_forward")
+        ctx.save_for_backward(a, b, w)
+        ctx.in_dtypes = (u0.dtype, u.dtype, skip_weight.dtype, skip_weight.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = L.load()
+        a, b, w = ctx.saved_tensors
+        g = g.to(b.dtype).contiguous()
+        g_a, g_b = torch.empty_like(a), torch.empty_like(b)
+        g_w = torch.empty(1, dtype=torch.float32, device=b.device)
+        ws = _workspace(lib.pde_skip_blend_backward_workspace_bytes(b.numel()), b.device)
+        with torch.cuda.device(b.device):
+            L.check(lib.pde_skip_blend_backward(b.numel(), _io_dtype(b), _ptr(g), _ptr(a), _ptr(b), _ptr(w), _ptr(g_a), _ptr(g_b),
+                                                _ptr(g_w), _ptr(ws), ws.numel(), _stream()), "pde_skip_blend_backward")
+        d0, d1, dw, shw = ctx.in_dtypes
+        return g_a.to(d0), g_b.to(d1), g_w.to(dw).reshape(shw)
+
+
+def skip_blend(u0, u, skip_weight):
+    """``sigmoid(skip_weight) * u0 + (1 - sigmoid(skip_weight)) * u`` — SVHN.py:73-74, one pass."""
+    if u.numel() == 0:
+        s = torch.sigmoid(skip_weight)
+        return s * u0 + (1 - s) * u
+    return _SkipBlendFn.apply(u0, u, skip_weight)
 
 
 # --------------------------------------------------------------------------- timing

@@ -186,8 +186,7 @@ class SvhnDiffusionLayer(_AdiBase):
     def forward(self, u):
         original_u = u
         u = self._diffuse_mixed(u, self._schedule(), self.channel_coupling, "post")
-        s = torch.sigmoid(self.skip_weight)
-        return s * original_u + (1 - s) * u
+        return F_.skip_blend(original_u, u, self.skip_weight)          # SVHN.py:73-74
 
 
 class EnhancedDiffusionLayer(_AdiBase):

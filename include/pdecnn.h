@@ -182,6 +182,16 @@ int pde_channel_mix_backward_steps(int32_t B, int32_t C, int32_t HW, int32_t io_
                                    void* workspace, size_t workspace_bytes,
                                    int32_t accumulate, int32_t finalize, void* stream);
 
+/* SVHN.py:73-74 skip connection: out = s*u0 + (1-s)*u with s = sigmoid(*skip_weight) (device scalar), n
+ * elements of io_dtype, one pass.  Backward: g_u0 = s*g, g_u = (1-s)*g,
+ * *g_skip_weight = s(1-s) * sum g*(u0-u) (deterministic two-stage sum). */
+int pde_skip_blend_forward(int64_t n, int32_t io_dtype, const void* u0, const void* u,
+                           const float* skip_weight, void* out, void* stream);
+size_t pde_skip_blend_backward_workspace_bytes(int64_t n);
+int pde_skip_blend_backward(int64_t n, int32_t io_dtype, const void* g, const void* u0, const void* u,
+                            const float* skip_weight, void* g_u0, void* g_u, float* g_skip_weight,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- K2: explicit 5-point layers --------------------------- */
 
 /* tiny_imagenet.py:34-72, one relaxed explicit step:

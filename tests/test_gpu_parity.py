@@ -337,6 +337,34 @@ def test_inside_autocast(amp_dtype):
     assert G.rel_err(y.detach().float().cpu(), y32.detach().cpu()) <= (2e-2 if amp_dtype == torch.bfloat16 else 5e-3)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_skip_blend_vs_torch(dtype):
+    """SVHN.py:73-74 in one pass, against the torch expression (values and all three gradients)."""
+    from cnn_with_pde_amd import functional as F_
+    g = torch.Generator().manual_seed(11)
+    shape = (7, 3, 32, 32)                      # 21504 elements, plus a ragged size below
+    for n_extra in (0, 5):
+        u0 = torch.randn(*shape, generator=g)
+        u = torch.randn(*shape, generator=g)
+        gy = torch.randn(*shape, generator=g)
+        if n_extra:
+            u0, u, gy = (x.flatten()[:-3].clone() for x in (u0, u, gy))
+        w = torch.tensor(0.9)
+        a, b, ww = (x.double().requires_grad_(True) for x in (u0.to(dtype), u.to(dtype), w))
+        s = torch.sigmoid(ww)
+        ref = s * a + (1 - s) * b
+        ref.backward(gy.to(dtype).double())
+        ad, bd = u0.to(dtype).cuda().requires_grad_(True), u.to(dtype).cuda().requires_grad_(True)
+        wd = w.cuda().requires_grad_(True)
+        out = F_.skip_blend(ad, bd, wd)
+        assert out.dtype == dtype
+        out.backward(gy.to(dtype).cuda())
+        tol = 1e-6 if dtype == torch.float32 else 6e-3
+        assert G.rel_err(out.detach().float().cpu(), ref.detach()) <= tol
+        assert G.rel_err(ad.grad.float().cpu(), a.grad) <= tol and G.rel_err(bd.grad.float().cpu(), b.grad) <= tol
+        assert abs(float(wd.grad) - float(ww.grad)) <= 2e-5 * max(1.0, abs(float(ww.grad)))
+
+
 def test_empty_batch_passes_through():
     """B = 0 (the last, empty shard of a ragged split): the reference's torch ops return an empty tensor
     and zero parameter gradients; so do the layers, without a launch."""
