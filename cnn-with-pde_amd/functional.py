@@ -267,7 +267,7 @@ class _AdiMixedFn(torch.autograd.Function):
         ctx.cfg = (steps, mode, smooth3, clamp_max, eps, ckpt)
         ctx.param_shapes = [t.shape for t in (ab, bb, asl, bsl)]
         ctx.M_dtype = M.dtype
-        return y.clone() if not need_grad else y
+        return y.clone()        # never a view of the saved states: callers may modify their result in place
 
     @staticmethod
     def backward(ctx, gy):
