@@ -208,7 +208,7 @@ def test_mixed_layer_call_equals_per_step_composition(mode, split, ck):
     import cnn_with_pde_amd as P
     from cnn_with_pde_amd import functional as F_
     g = torch.Generator().manual_seed(77)
-    B, C, N, K = 9, 5, 32, 4
+    B, C, N, K = (9, 5, 32, 4) if ck != 0b1 else (1, 2, 28, 1)      # also: a single step, a single sample
     steps = P.adi_schedule(0.05, 1.0, 1.0, K, split)
     mk = lambda: [(1 + 0.2 * torch.randn(C, N, N, generator=g)).cuda().requires_grad_(True) for _ in range(2)] + \
                  [(0.5 * torch.randn(C, N, N, generator=g)).cuda().requires_grad_(True) for _ in range(2)]
