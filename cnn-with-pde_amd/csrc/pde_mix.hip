@@ -432,10 +432,11 @@ __global__ __launch_bounds__(256) void mix_frag_kernel(const float* __restrict__
     const int i = 32 * it + (ln & 31), k = 2 * ks + (ln >> 5);
     frag[e] = M[k * C + i];
 }
-bool mfma_fused_ok(int C, int HW) { return (C == 64 || C == 128) && (HW % 4) == 0; }
+bool mfma_fused_ok(int C, int HW) { return (C == 32 || C == 64 || C == 96 || C == 128) && (HW % 4) == 0; }
 int fused_splits(int B, int C, int HW) {
     const long chunks = (long)B * ((HW + kGmKP - 1) / kGmKP);
-    const long want = C == 64 ? 768 : 512;           // workgroups resident at once: 3 per CU (50 KB of LDS) / 2 (68 KB)
+    // workgroups resident at once: C=32 one-wave groups, 6 per CU (21 KB of LDS); 64: 3 (50 KB); 96: 1 (87 KB); 128: 2 (68 KB)
+    const long want = C == 32 ? 1536 : C == 64 ? 768 : C == 96 ? 256 : 512;
     return (int)(chunks < want ? chunks : want);
 }
 template <typename IO, int C, int W, bool WLDS>
@@ -450,7 +451,7 @@ void launch_fused(const void* u, const void* g, const float* M, void* gu, float*
 }
 
 bool mfma_apply_ok(int C, int HW) { return (C % 32) == 0 && C <= 128 && (HW % 4) == 0; }   // W fragments: C*C*4 B of LDS
-bool mfma_gm_ok(int C, int HW) { return (C == 64 || C == 128) && (HW % 4) == 0; }
+bool mfma_gm_ok(int C, int HW) { return (C % 32) == 0 && C <= 128 && (HW % 4) == 0; }   // up to 16 tiles: 4 per wave
 int gm_mfma_splits(int B, int HW) {
     const long chunks = (long)B * ((HW + kGmKP - 1) / kGmKP);
     return (int)(chunks < 512 ? chunks : 512);
@@ -539,10 +540,14 @@ int pde_channel_mix_backward_steps(int32_t B, int32_t C, int32_t HW, int32_t io_
     if (mfma_fused_ok(C, HW) && getenv("PDE_MIX_UNFUSED") == nullptr) {
         const int nsplit = fused_splits(B, C, HW);
         if (io_dtype == PDE_IO_F32) {
-            if (C == 64) launch_fused<float, 64, 4, true>(u, gout, M, gu, part, B, HW, nsplit, accumulate, st);
+            if (C == 32) launch_fused<float, 32, 1, true>(u, gout, M, gu, part, B, HW, nsplit, accumulate, st);
+            else if (C == 64) launch_fused<float, 64, 4, true>(u, gout, M, gu, part, B, HW, nsplit, accumulate, st);
+            else if (C == 96) launch_fused<float, 96, 3, true>(u, gout, M, gu, part, B, HW, nsplit, accumulate, st);
             else launch_fused<float, 128, 8, false>(u, gout, M, gu, part, B, HW, nsplit, accumulate, st);
         } else {
-            if (C == 64) launch_fused<bf16s, 64, 4, true>(u, gout, M, gu, part, B, HW, nsplit, accumulate, st);
+            if (C == 32) launch_fused<bf16s, 32, 1, true>(u, gout, M, gu, part, B, HW, nsplit, accumulate, st);
+            else if (C == 64) launch_fused<bf16s, 64, 4, true>(u, gout, M, gu, part, B, HW, nsplit, accumulate, st);
+            else if (C == 96) launch_fused<bf16s, 96, 3, true>(u, gout, M, gu, part, B, HW, nsplit, accumulate, st);
             else launch_fused<bf16s, 128, 8, false>(u, gout, M, gu, part, B, HW, nsplit, accumulate, st);
         }
         if (finalize) hipLaunchKernelGGL(mix_gm_reduce_kernel, dim3((C * C + 31) / 32), dim3(256), 0, st, part, gM, C * C, nsplit);
@@ -580,7 +585,7 @@ int pde_channel_mix_backward_steps(int32_t B, int32_t C, int32_t HW, int32_t io_
             hipLaunchKernelGGL((mix_gm_kernel<bf16s>), dim3(tiles * tiles, nsplit), dim3(256), 0, st, (const bf16s*)u,
                                (const bf16s*)gout, part, B, C, HW, nsplit, accumulate);
     }
-    hipLaunchKernelGGL(mix_gm_reduce_kernel, dim3((C * C + 31) / 32), dim3(256), 0, st, part, gM, C * C, nsplit);
+    if (finalize) hipLaunchKernelGGL(mix_gm_reduce_kernel, dim3((C * C + 31) / 32), dim3(256), 0, st, part, gM, C * C, nsplit);
     return check_launch();
 }
 
