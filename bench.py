@@ -104,10 +104,12 @@ def cpu_baseline(C, N, steps, sample_B):
     nb = int(max(2, min(sample_B, 2 * 20.0 / max(probe, 1e-3))))
     print(f"[bench] cpu_baseline probe {probe:.1f} s for 2 samples; timing {nb} samples", file=sys.stderr, flush=True)
     dt = once(nb)
+    runs = [(nb, dt)]
     if dt < 8.0 and nb < sample_B:              # batching made it cheaper than the probe said: aim at ~15 s
-        nb = int(min(sample_B, max(nb + 1, nb * 15.0 / max(dt, 1e-3))))
-        print(f"[bench] cpu_baseline {dt:.1f} s was short; timing {nb} samples", file=sys.stderr, flush=True)
-        dt = once(nb)
+        nb2 = int(min(sample_B, max(nb + 1, nb * 15.0 / max(dt, 1e-3))))
+        print(f"[bench] cpu_baseline {dt:.1f} s was short; timing {nb2} samples", file=sys.stderr, flush=True)
+        runs.append((nb2, once(nb2)))
+    nb, dt = max(runs, key=lambda r: r[0] / r[1])        # the CPU path at its best batch (large ones thrash its autograd graph)
     out = {"value": nb / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
            "sample": f"B={nb} of the same (C={C},{N}x{N},{steps} steps) workload, one fwd+bwd, "
                      f"oracle/pde_oracle.py in reference-faithful mode ({dt:.1f} s on {cores} threads)"}
@@ -139,7 +141,7 @@ def main():
     ap.add_argument("--num-steps", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=256, help="upper bound of the CPU baseline sample (samples)")
+    ap.add_argument("--cpu-sample", type=int, default=160, help="upper bound of the CPU baseline sample (samples)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
