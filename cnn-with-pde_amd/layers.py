@@ -24,6 +24,7 @@ import torch
 import torch.nn as nn
 
 from . import functional as F_
+from . import _lib as L
 
 __all__ = ["MnistDiffusionLayer", "FashionDiffusionLayer", "SvhnDiffusionLayer", "EnhancedDiffusionLayer",
            "LearnableDiffusionLayer", "ImprovedDiffusionLayer", "PDELayer"]
@@ -85,6 +86,18 @@ class _AdiBase(nn.Module):
         return F_.adi_diffuse(u, *args, sweeps, checkpoints=ck, **kw)
 
 
+    def _run(self, u, steps, M=None, mode=None):
+        """All steps of the layer.  One launch sequence holds at most PDE_MAX_SWEEPS sweeps: longer schedules
+        (num_steps > 32 Strang steps) are cut into groups of whole steps, chained through autograd."""
+        per = max(1, L.PDE_MAX_SWEEPS // len(steps[0]))
+        for i in range(0, len(steps), per):
+            grp = steps[i:i + per]
+            if M is None:
+                u = self._diffuse(u, [s for st in grp for s in st])
+            else:
+                u = self._diffuse_mixed(u, grp, M, mode)
+        return u
+
     def _diffuse_mixed(self, u, steps, M, mode):
         """All steps of a layer with a channel operator between them (functional.adi_diffuse_mixed), with
         the same lagged choice of checkpoints as ``_diffuse`` (one step-local mask for every step)."""
@@ -103,7 +116,7 @@ class _AdiBase(nn.Module):
                 bits |= F_.plan_checkpoints(km[k * sps:(k + 1) * sps], F_.CKPT_AMAX / 2)
             return bits
         cache = self.__dict__.setdefault("_kmax_cache", {})
-        key = ("mixed", len(steps), sps, u.device)
+        key = ("mixed", len(steps), sps, steps[0][0].t, u.device)
         old = cache.get(key)
         if old is None:                                    # first call only: wait for the coefficients
             flat = [s for st in steps for s in st]
@@ -135,7 +148,7 @@ class MnistDiffusionLayer(_AdiBase):
     def forward(self, u):
         if u.dim() != 4 or u.shape[1] != 1:
             raise ValueError(f"expected (B,1,{self.size},{self.size}), got {tuple(u.shape)}")
-        return self._diffuse(u, [s for step in self._schedule() for s in step])
+        return self._run(u, self._schedule())
 
     def get_numerical_stability_info(self):
         """mnist_test.py:200-219."""
@@ -164,7 +177,7 @@ class FashionDiffusionLayer(_AdiBase):
     def forward(self, u):
         if u.dim() != 4 or u.shape[1] != 1:
             raise ValueError(f"expected (B,1,{self.size},{self.size}), got {tuple(u.shape)}")
-        return self._diffuse(u, [s for step in self._schedule() for s in step])
+        return self._run(u, self._schedule())
 
 
 class SvhnDiffusionLayer(_AdiBase):
@@ -185,7 +198,7 @@ class SvhnDiffusionLayer(_AdiBase):
 
     def forward(self, u):
         original_u = u
-        u = self._diffuse_mixed(u, self._schedule(), self.channel_coupling, "post")
+        u = self._run(u, self._schedule(), self.channel_coupling, "post")
         return F_.skip_blend(original_u, u, self.skip_weight)          # SVHN.py:73-74
 
 
@@ -220,8 +233,8 @@ class EnhancedDiffusionLayer(_AdiBase):
     def forward(self, u):
         steps = self._schedule()
         if not self.channel_mixing_enabled:
-            return self._diffuse(u, [s for step in steps for s in step])
-        return self._diffuse_mixed(u, steps, self.channel_mixing, "pre")
+            return self._run(u, steps)
+        return self._run(u, steps, self.channel_mixing, "pre")
 
 
 class LearnableDiffusionLayer(EnhancedDiffusionLayer):

@@ -106,6 +106,22 @@ def test_every_line_length_vs_oracle(N):
     _compare(strang, lambda a, p: O.adi_forward(a, p, O.mnist_spec(N, 0.01, 1.0, 1.0, 3)), u, gy)
 
 
+def test_schedules_longer_than_one_launch():
+    """num_steps = 40 Strang steps = 120 sweeps > PDE_MAX_SWEEPS: the layers chain two launch sequences."""
+    import cnn_with_pde_amd as P
+    g = torch.Generator().manual_seed(404)
+    layer = quiet(P.EnhancedDiffusionLayer, 32, 2, dt=0.004, num_steps=40, channel_mixing_enabled=False)
+    _perturb(layer, g, 0.2, 0.3)
+    with torch.no_grad():
+        layer.channel_mixing.copy_(torch.eye(2))
+    u = torch.randn(3, 2, 32, 32, generator=g)
+    gy = torch.randn(3, 2, 32, 32, generator=g)
+    _compare(layer, lambda a, p: O.adi_forward(a, p, O.cifar10_spec(32, 2, dt=0.004, num_steps=40)), u, gy, tol=2e-5)
+    mixed = quiet(P.EnhancedDiffusionLayer, 32, 2, dt=0.004, num_steps=40)
+    _perturb(mixed, g, 0.2, 0.3)
+    _compare(mixed, lambda a, p: O.adi_forward(a, p, O.cifar10_spec(32, 2, dt=0.004, num_steps=40)), u, gy, tol=2e-5)
+
+
 def test_unsupported_sizes_fail_loudly():
     """N outside the instantiated set is an error from the C ABI, never a silent other path."""
     import cnn_with_pde_amd as P
