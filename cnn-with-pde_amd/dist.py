@@ -55,18 +55,24 @@ class GradBucket:
         return self.flat.numel() * 4
 
     def allreduce(self, average: bool = True, group=None) -> None:
+        """Few launches per step: one gather of the gradients into the flat buffer, ONE collective, one scatter back."""
         views = list(self.flat.split(self.sizes))
-        for v, p in zip(views, self.params):
-            if p.grad is None:
-                v.zero_()
-            else:
-                v.copy_(p.grad.reshape(-1))
+        missing = [i for i, p in enumerate(self.params) if p.grad is None]
+        for i in missing:
+            self.params[i].grad = torch.zeros_like(self.params[i], dtype=torch.float32)
+        grads = [p.grad for p in self.params]
+        if all(g.dtype == torch.float32 and g.is_contiguous() for g in grads):
+            torch.cat([g.reshape(-1) for g in grads], out=self.flat)           # one launch
+        else:
+            for v, g in zip(views, grads):
+                v.copy_(g.reshape(-1))
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
             if average:
                 self.flat.div_(dist.get_world_size(group))
-        for v, p in zip(views, self.params):
-            if p.grad is None:
-                p.grad = v.reshape(p.shape).clone()
-            else:
-                p.grad.copy_(v.reshape(p.shape))
+        shaped = [v.view(p.shape) for v, p in zip(views, self.params)]
+        if all(g.dtype == torch.float32 for g in grads):
+            torch._foreach_copy_(grads, shaped)                               # one launch (fused foreach)
+        else:
+            for g, v in zip(grads, shaped):
+                g.copy_(v)
