@@ -44,3 +44,24 @@ def test_layer_parameters_receive_updates():
     moved = {n: float((p.detach() - before[n]).abs().max()) for n, p in model.diff.named_parameters()}
     assert all(v > 0 for v in moved.values()), moved
     assert isinstance(model.diff, P.MnistDiffusionLayer)
+
+
+def test_grad_bucket_round_trip_on_gpu():
+    """GradBucket without a process group: gather -> (no collective) -> scatter leaves every .grad as it was,
+    through the one-launch cat / fused foreach copy paths; parameters without a gradient get zeros."""
+    import cnn_with_pde_amd as P
+    mod = _load()
+    torch.manual_seed(1)
+    model = mod.MnistLike().cuda()
+    x = torch.randn(16, 1, 28, 28, device="cuda")
+    model(x).square().mean().backward()
+    model.fc2.bias.grad = None
+    before = {n: (p.grad.clone() if p.grad is not None else None) for n, p in model.named_parameters()}
+    bucket = P.GradBucket(model.parameters())
+    bucket.allreduce(average=True)
+    for n, p in model.named_parameters():
+        if before[n] is None:
+            assert p.grad is not None and float(p.grad.abs().max()) == 0.0
+        else:
+            assert torch.equal(p.grad, before[n]), n
+    assert bucket.nbytes() == 4 * sum(p.numel() for p in model.parameters())
