@@ -231,12 +231,7 @@ template <> struct IoTraits<float> {
 };
 struct bf16_t { unsigned short v; };
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned int)h << 16); }
-__device__ __forceinline__ unsigned short f32_to_bf16(float f) {      // round to nearest even, NaN kept
-    unsigned int u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) { return f32_to_bf16_hw(f); }
 template <> struct IoTraits<bf16_t> {
     __device__ static __forceinline__ float4 load4(const bf16_t* p) {
         typedef unsigned short u4 __attribute__((ext_vector_type(4)));

@@ -9,12 +9,7 @@ namespace {
 
 struct bf16v { unsigned short v; };
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned int)h << 16); }
-__device__ __forceinline__ unsigned short f2bf(float f) {
-    unsigned int u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
+__device__ __forceinline__ unsigned short f2bf(float f) { return f32_to_bf16_hw(f); }
 template <typename IO> struct Vec;                      // 8 elements per thread and access
 template <> struct Vec<float> {
     static constexpr int kBytes = 32;

@@ -33,12 +33,7 @@ template <> struct Io<float> {
 struct bf16s { unsigned short v; };
 template <> struct Io<bf16s> {
     __device__ static __forceinline__ float ld(const bf16s* p) { return __uint_as_float((unsigned int)p->v << 16); }
-    __device__ static __forceinline__ void st(bf16s* p, float f) {
-        unsigned int u = __float_as_uint(f);
-        if ((u & 0x7fffffffu) > 0x7f800000u) { p->v = (unsigned short)((u >> 16) | 0x40); return; }
-        u += 0x7fffu + ((u >> 16) & 1u);
-        p->v = (unsigned short)(u >> 16);
-    }
+    __device__ static __forceinline__ void st(bf16s* p, float f) { p->v = f32_to_bf16_hw(f); }
 };
 
 constexpr int kOC = 8;   // output channels per pass

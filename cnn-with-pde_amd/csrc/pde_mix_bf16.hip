@@ -30,12 +30,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kPx = 64;                 // pixels per tile
 constexpr int kRow = 144;               // bytes per tile row: 128 + 16 pad (16 consecutive rows hit 64 distinct banks)
 
-__device__ __forceinline__ unsigned short f2bf(float f) {      // round to nearest even, NaN kept
-    unsigned int u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
+__device__ __forceinline__ unsigned short f2bf(float f) { return f32_to_bf16_hw(f); }
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned int)h << 16); }
 
 // hi/lo bf16 fragments of M for the B operand, in LDS: [piece][tile][k-step][lane][8].
