@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-# PDECNN_LIB: developer override (timing-only ablation builds of tools/ablate.sh)
+# PDECNN_LIB: developer override (an alternative build of the same library, e.g. make WAVES=4)
 LIB_PATH = os.environ.get("PDECNN_LIB") or os.path.join(HERE, "lib", "libpdecnn_hip.so")
 
 PDE_MAX_SWEEPS = 96
@@ -45,7 +45,7 @@ _D = C.POINTER(PdeAdiDesc)
 SIGNATURES = {
     "pde_adi_forward_workspace_bytes": (_sz, [_D]),
     "pde_adi_backward_workspace_bytes": (_sz, [_D, _i32]),
-    "pde_adi_forward": (C.c_int, [_D, _vp, _vp, _fp, _fp, _fp, _fp, _fp, _vp, _sz, _vp]),
+    "pde_adi_forward": (C.c_int, [_D, _vp, _vp, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _vp, _sz, _vp]),
     "pde_adi_backward": (C.c_int, [_D, _vp, _vp, _vp, C.POINTER(C.c_uint64), _vp, _fp, _fp, _fp, _fp,
                                    _fp, _fp, _fp, _fp, _vp, _vp, _sz, _vp]),
     "pde_adi_kappa_max": (C.c_int, [_D, _fp, _fp, _fp, _fp, _fp, _vp]),
@@ -56,7 +56,7 @@ SIGNATURES = {
     "pde_adi_backward_step": (C.c_int, [_D, _i32, _i32, _vp, _vp, _vp, C.POINTER(C.c_uint64), _vp, _vp, _vp, _sz,
                                         _i32, _vp]),
     "pde_adi_param_grads": (C.c_int, [_D, _i32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _vp, _vp]),
-    "pde_adi_mixed_forward": (C.c_int, [_D, _i32, _i32, _vp, _vp, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _sz, _vp]),
+    "pde_adi_mixed_forward": (C.c_int, [_D, _i32, _i32, _vp, _vp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _vp, _sz, _vp]),
     "pde_adi_mixed_backward_workspace_bytes": (_sz, [_D, _i32, _i32]),
     "pde_adi_mixed_backward": (C.c_int, [_D, _i32, _i32, _vp, _vp, _vp, _fp, C.POINTER(C.c_uint64), _vp, _fp, _fp, _fp, _fp,
                                          _fp, _fp, _fp, _fp, _fp, _vp, _vp, _sz, _vp]),

@@ -54,6 +54,18 @@ Timing& timing() {
     return t;
 }
 
+int ensure_dynamic_lds(const void* kernel, int bytes, unsigned long long& done) {
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PDE_E_LAUNCH;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!((done >> dev) & 1ull)) {
+        if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return PDE_E_LAUNCH;
+        done |= 1ull << dev;
+    }
+    return PDE_OK;
+}
+
 namespace {
 
 // ------------------------------------------------------------------------------------
@@ -449,6 +461,18 @@ std::mutex& launch_mutex() {
     return m;
 }
 
+// The per-sweep coefficient maxima leave for the host right behind the factor kernel, BEFORE the sweep
+// launches: whoever plans checkpoints from them waits for microseconds, not for the layer's forward.
+int publish_kmax(const float* kmax_dev, float* kmax_host, void* event, int n, hipStream_t st) {
+    if (kmax_host) {
+        if (!kmax_dev) return PDE_E_BADARG;
+        if (hipMemcpyAsync(kmax_host, kmax_dev, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess)
+            return PDE_E_LAUNCH;
+    }
+    if (event && hipEventRecord(static_cast<hipEvent_t>(event), st) != hipSuccess) return PDE_E_LAUNCH;
+    return PDE_OK;
+}
+
 // which compile-time step pattern the schedule follows
 int split_of(const PdeAdiDesc* d) {
     const int S = d->num_sweeps;
@@ -638,8 +662,8 @@ size_t pde_adi_backward_workspace_bytes(const PdeAdiDesc* d, int32_t num_checkpo
 }
 
 int pde_adi_forward(const PdeAdiDesc* d, const void* u, void* y, const float* alpha_base, const float* beta_base,
-                    const float* alpha_slope, const float* beta_slope, float* kappa_max, void* workspace,
-                    size_t workspace_bytes, void* stream) {
+                    const float* alpha_slope, const float* beta_slope, float* kappa_max, float* kappa_max_host,
+                    void* kappa_event, void* workspace, size_t workspace_bytes, void* stream) {
     int rc = check_desc(d);
     if (rc != PDE_OK) return rc;
     if (!u || !y || !alpha_base || !beta_base || !alpha_slope || !beta_slope || !workspace) return PDE_E_BADARG;
@@ -650,6 +674,8 @@ int pde_adi_forward(const PdeAdiDesc* d, const void* u, void* y, const float* al
     int* varying = reinterpret_cast<int*>(static_cast<char*>(workspace) + coef_bytes(d) + tab_bytes());
     hipLaunchKernelGGL(adi_zero_kernel, dim3(1), dim3(256), 0, st, varying, d->C, kappa_max, d->num_sweeps);
     rc = launch_factor(d, alpha_base, beta_base, alpha_slope, beta_slope, coef, tab, varying, kappa_max, st);
+    if (rc != PDE_OK) return rc;
+    rc = publish_kmax(kappa_max, kappa_max_host, kappa_event, d->num_sweeps, st);
     if (rc != PDE_OK) return rc;
     return launch_fwd_sweeps(d, u, y, coef, tab, st);
 }
@@ -796,11 +822,13 @@ static size_t state_bytes(const PdeAdiDesc* d) {
 
 int pde_adi_mixed_forward(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t mode, const void* u, void* states,
                           const float* M, const float* alpha_base, const float* beta_base, const float* alpha_slope,
-                          const float* beta_slope, float* kappa_max, void* steps_workspace, size_t workspace_bytes,
-                          void* stream) {
+                          const float* beta_slope, float* kappa_max, float* kappa_max_host, void* kappa_event,
+                          void* steps_workspace, size_t workspace_bytes, void* stream) {
     if (!u || !states || !M || (mode != 1 && mode != 2)) return PDE_E_BADARG;
     int rc = pde_adi_factor_steps(d, sweeps_per_step, alpha_base, beta_base, alpha_slope, beta_slope, kappa_max,
                                   steps_workspace, workspace_bytes, stream);
+    if (rc != PDE_OK) return rc;
+    rc = publish_kmax(kappa_max, kappa_max_host, kappa_event, d->num_sweeps, static_cast<hipStream_t>(stream));
     if (rc != PDE_OK) return rc;
     const int K = d->num_sweeps / sweeps_per_step, HW = d->N * d->N;
     const size_t sb = state_bytes(d);
@@ -899,6 +927,7 @@ int pde_timing_enable(int32_t on) {
 }
 
 int pde_timing_read(double* fwd_ms_sum, int64_t* fwd_launches, double* bwd_ms_sum, int64_t* bwd_launches) {
+    std::lock_guard<std::mutex> lk(launch_mutex());
     for (auto& p : pending()) {
         float ms = 0.f;
         (void)hipEventSynchronize(p.e1);

@@ -357,9 +357,6 @@ __device__ __forceinline__ void rows_to_plane(const P (&v)[Geo<N>::M], float* T,
 template <int N, int C, class P>
 __device__ __forceinline__ void relayout(P (&v)[Geo<N>::M], float* T, int l, int hf) {
     constexpr int M = Geo<N>::M;
-#if defined(PDE_ABL) && PDE_ABL == 1
-    return;                                   // ablation: no re-layout (results wrong, timing only)
-#endif
     if (l < N) {
         const int mypos = (l < M) ? l : kHalfPad + (N - 1 - l);
         float* dst = T + hf * M * kLineStride + mypos;
@@ -763,11 +760,7 @@ __device__ __forceinline__ void adi_bwd_body(const SweepArgs& a, int blk) {
             solve_adj<M, J>(r, ce, cinv, cjn, hf);
             relayout_all<N, J>(r, T, l, hf);
             load_half<M>(crow + kB_KapX, ckap);
-#if !(defined(PDE_ABL) && PDE_ABL == 2)
             state_y<N, J, MASKED>(r, x, Ay, ckap, rec, l, hf, a.smooth3);
-#else
-            Ay[0] += pk_hsum(r[0]);
-#endif
             if (dts != 0.f) {
 #pragma unroll
                 for (int k = 0; k < M; ++k) Ty[k] = fmaf(dts, Ay[k], Ty[k]);
@@ -779,11 +772,7 @@ __device__ __forceinline__ void adi_bwd_body(const SweepArgs& a, int blk) {
             load_half<M>(crow + kB_Inv, cinv);
             solve_adj<M, J>(r, ce, cinv, cjn, hf);
             load_half<M>(crow + kB_KapX, ckap);
-#if !(defined(PDE_ABL) && PDE_ABL == 2)
             state_x<M, J, MASKED>(r, x, Ax, xin, ckap, rec, l, hf, a.smooth3);
-#else
-            Ax[0] += pk_hsum(xin) + pk_hsum(r[0]);
-#endif
             if (dts != 0.f) {
 #pragma unroll
                 for (int k = 0; k < M; ++k) Tx[k] = fmaf(dts, Ax[k], Tx[k]);

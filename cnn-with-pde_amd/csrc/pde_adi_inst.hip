@@ -2,8 +2,6 @@
 #include "pde_adi_dev.h"
 #include "pde_adi_launch.h"
 
-#include <mutex>
-
 #ifndef PDE_INST_N
 #error "compile with -DPDE_INST_N=<line length>"
 #endif
@@ -14,22 +12,10 @@
 namespace pde {
 namespace {
 
-// The dynamic-LDS limit is a per-device attribute of the kernel: set it once per (kernel, device).
 template <typename K>
 int launch(K kernel, const SweepArgs& sa, int grid, size_t lds, hipStream_t st) {
-    static std::mutex mu;
-    static unsigned long long configured = 0;       // bit d: done on device d (one static per kernel instantiation)
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PDE_E_LAUNCH;
-    {
-        std::lock_guard<std::mutex> lk(mu);
-        if (!((configured >> dev) & 1ull)) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds) != hipSuccess)
-                return PDE_E_LAUNCH;
-            configured |= 1ull << dev;
-        }
-    }
+    static unsigned long long configured = 0;       // one static per kernel instantiation
+    if (ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), (int)lds, configured) != PDE_OK) return PDE_E_LAUNCH;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), lds, st, sa);
     return check_launch();
 }

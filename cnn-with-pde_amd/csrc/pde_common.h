@@ -66,6 +66,13 @@ struct Timing {
 };
 Timing& timing();
 
-inline int check_launch() { return hipGetLastError() == hipSuccess ? PDE_OK : PDE_E_LAUNCH; }
+// Peek, not Get: the caller's framework (PyTorch) owns the thread's sticky error state; the library only
+// reports that one of its launches failed and leaves the state for the owner to read.
+inline int check_launch() { return hipPeekAtLastError() == hipSuccess ? PDE_OK : PDE_E_LAUNCH; }
+
+// The dynamic-LDS limit is a per-device attribute of a kernel: set it once per (kernel, device).  `done` is the
+// caller's per-kernel bit mask (bit d: configured on device d); one process-wide mutex guards all of them
+// (autograd runs one backward thread per device, so two devices may arrive here together).
+int ensure_dynamic_lds(const void* kernel, int bytes, unsigned long long& done);
 
 }  // namespace pde

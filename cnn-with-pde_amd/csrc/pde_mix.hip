@@ -16,14 +16,7 @@ namespace pde {
 namespace {
 
 // dynamic-LDS limit: a per-device attribute of a kernel, set once per (kernel, device)
-inline void ensure_lds(const void* kernel, int bytes, unsigned long long& done) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
-    if (!((done >> dev) & 1ull)) {
-        (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        done |= 1ull << dev;
-    }
-}
+inline void ensure_lds(const void* kernel, int bytes, unsigned long long& done) { (void)ensure_dynamic_lds(kernel, bytes, done); }
 
 template <typename IO> struct Io;
 template <> struct Io<float> {
@@ -503,7 +496,12 @@ int pde_channel_mix_forward(int32_t B, int32_t C, int32_t HW, int32_t io_dtype, 
 
 size_t pde_channel_mix_backward_workspace_bytes(int32_t B, int32_t C, int32_t HW) {
     if (B <= 0 || C <= 0 || HW <= 0) return 0;
-    const int n = mfma_fused_ok(C, HW) ? fused_splits(B, C, HW) : mfma_gm_ok(C, HW) ? gm_mfma_splits(B, HW) : gm_splits(B, C, HW);
+    // the maximum over every path a call with these dimensions can take (tensor type, PDE_MIX_* switches):
+    // the caller sizes one workspace without saying which tensor type it will pass
+    int n = gm_splits(B, C, HW);
+    if (mfma_fused_ok(C, HW)) n = n > fused_splits(B, C, HW) ? n : fused_splits(B, C, HW);
+    if (mfma_gm_ok(C, HW)) n = n > gm_mfma_splits(B, HW) ? n : gm_mfma_splits(B, HW);
+    if (mix_bf16_ok(C, HW)) n = n > mix_bf16_splits(B, C, HW) ? n : mix_bf16_splits(B, C, HW);
     return (size_t)(n + 1) * C * C * sizeof(float);      // partial matrices + one fragment table
 }
 

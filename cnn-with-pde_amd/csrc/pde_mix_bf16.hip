@@ -246,14 +246,7 @@ __global__ __launch_bounds__(C * 4) void mix_bwd_bf16_kernel(const unsigned shor
     }
 }
 
-inline void ensure_lds(const void* kernel, int bytes, unsigned long long& done) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
-    if (!((done >> dev) & 1ull)) {
-        (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        done |= 1ull << dev;
-    }
-}
+inline void ensure_lds(const void* kernel, int bytes, unsigned long long& done) { (void)ensure_dynamic_lds(kernel, bytes, done); }
 
 template <int C>
 void launch_apply(const void* u, const float* M, void* out, int B, int HW, int trans, hipStream_t st) {

@@ -151,6 +151,15 @@ def kappa_max_async(u_like, alpha_base, beta_base, alpha_time_coeff, beta_time_c
     return host, ev
 
 
+def _kmax_channel(n: int):
+    """Pinned host buffer and a created event for the early copy of the per-sweep coefficient maxima
+    (pde_adi_forward records the event itself, right behind the factorisation kernel)."""
+    host = torch.empty(n, dtype=torch.float32, pin_memory=True)
+    ev = torch.cuda.Event()
+    ev.record()                     # creates the underlying hipEvent_t; the library re-records it
+    return host, ev
+
+
 class _AdiFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, u, ab, bb, asl, bsl, sweeps, smooth3, clamp_max, eps, ckpt, kmax_sink):
@@ -171,19 +180,16 @@ class _AdiFn(torch.autograd.Function):
         want_kmax = need_grad and (ckpt == "auto" or kmax_sink is not None)
         kdev = torch.empty(len(sweeps), dtype=torch.float32, device=u.device) if want_kmax else None
         with torch.cuda.device(u.device):
-            L.check(lib.pde_adi_forward(C.byref(d), _ptr(u), _ptr(y), *[_ptr(t) for t in p], _ptr(kdev),
+            # per-sweep maximum coefficient (a by-product of the factorisation kernel): copied to pinned host
+            # memory right behind that kernel, before the sweep launch, so whoever plans checkpoints from it
+            # waits for the factorisation only
+            host, ev = _kmax_channel(len(sweeps)) if want_kmax else (None, None)
+            L.check(lib.pde_adi_forward(C.byref(d), _ptr(u), _ptr(y), *[_ptr(t) for t in p], _ptr(kdev), _ptr(host),
+                                        C.c_void_p(ev.cuda_event if ev is not None else 0),
                                         _ptr(ws), ws.numel(), _stream()), "pde_adi_forward")
-            ctx.kmax_host = ctx.kmax_event = None
-            if want_kmax:
-                # per-sweep maximum coefficient (a by-product of the factorisation kernel), copied to
-                # the host asynchronously: whoever plans checkpoints reads it later without a stall
-                host = torch.empty(len(sweeps), dtype=torch.float32, pin_memory=True)
-                host.copy_(kdev, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record()
-                ctx.kmax_host, ctx.kmax_event = host, ev
-                if kmax_sink is not None:
-                    kmax_sink.append((host, ev))
+            ctx.kmax_host, ctx.kmax_event = host, ev
+            if want_kmax and kmax_sink is not None:
+                kmax_sink.append((host, ev))
         ctx.fwd_ws = ws if need_grad else None       # factorisation reused by the backward
         ctx.save_for_backward(y, u if (need_grad and ckpt != 0) else None, *p)
         ctx.cfg = (sweeps, smooth3, clamp_max, eps, ckpt)
@@ -248,18 +254,15 @@ class _AdiMixedFn(torch.autograd.Function):
         # states[k][0]: output of the step's first operator, states[k][1]: of its second (= input of step k+1)
         states = torch.empty((K, 2) + tuple(u.shape), dtype=u.dtype, device=u.device)
         with torch.cuda.device(u.device):
+            host, ev = _kmax_channel(len(sweeps)) if want_kmax else (None, None)
             L.check(lib.pde_adi_mixed_forward(C.byref(d), sps, 1 if mode == "pre" else 2, _ptr(u), _ptr(states), _ptr(Mf),
-                                              *[_ptr(t) for t in p], _ptr(kdev), _ptr(sws), sws.numel(), _stream()),
+                                              *[_ptr(t) for t in p], _ptr(kdev), _ptr(host),
+                                              C.c_void_p(ev.cuda_event if ev is not None else 0),
+                                              _ptr(sws), sws.numel(), _stream()),
                     "pde_adi_mixed_forward")
-            ctx.kmax_host = ctx.kmax_event = None
-            if want_kmax:
-                host = torch.empty(len(sweeps), dtype=torch.float32, pin_memory=True)
-                host.copy_(kdev, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record()
-                ctx.kmax_host, ctx.kmax_event = host, ev
-                if kmax_sink is not None:
-                    kmax_sink.append((host, ev))
+            ctx.kmax_host, ctx.kmax_event = host, ev
+            if want_kmax and kmax_sink is not None:
+                kmax_sink.append((host, ev))
         y = states[K - 1, 1]
         if need_grad:
             ctx.save_for_backward(u, states, Mf, *p)
@@ -298,7 +301,6 @@ class _AdiMixedFn(torch.autograd.Function):
                                                _ptr(Mf), mask, _ptr(g_a), *[_ptr(t) for t in p], *[_ptr(t) for t in gp],
                                                _ptr(gM), _ptr(ctx.sws), _ptr(ws), ws.numel(), _stream()),
                     "pde_adi_mixed_backward")
-        ctx.sws = None
         gp = [g.reshape(s) for g, s in zip(gp, ctx.param_shapes)]
         return (g_a, *gp, gM.to(ctx.M_dtype), None, None, None, None, None, None, None)
 

@@ -56,35 +56,52 @@ class _AdiBase(nn.Module):
         return (torch.clamp(alpha_t, min=self.stability_eps, max=self._clamp_max),
                 torch.clamp(beta_t, min=self.stability_eps, max=self._clamp_max))
 
-    #: "lagged" (default): the backward's checkpoints are chosen from the coefficients as they were
-    #: at the previous call (fetched asynchronously, no host stall; half the usual error budget to
-    #: cover one optimizer step of drift; the very first call waits once).  "auto": from the current
-    #: coefficients, at the price of one host wait per backward.  An int is an explicit bit mask.
-    checkpoint_policy = "lagged"
+    #: How the backward's checkpoints are chosen (functional.plan_checkpoints).
+    #: "auto" (default): from THIS call's coefficients.  Their per-sweep maxima leave the device right
+    #: behind the forward's factorisation kernel (pinned copy + event recorded inside pde_adi_forward, before
+    #: the sweep launch), so the backward's wait for them is over long before it is reached; exact after
+    #: load_state_dict, a change of dt/dx/dy, or any optimiser step.
+    #: "lagged": from the coefficients of the previous call in grad mode (never waits; half the error budget
+    #: to cover one optimiser step of drift).  The cache is dropped by load_state_dict and by a change of
+    #: dt/dx/dy/num_steps, but a LARGE in-place jump of the parameters between two calls is not seen: use it
+    #: only in loops whose parameters move by optimiser steps.
+    #: An int is an explicit bit mask.
+    checkpoint_policy = "auto"
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.__dict__.pop("_kmax_cache", None)              # a lagged plan made for the old parameters is void
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def _lagged_plan(self, key, u, args, kw, flat, plan):
+        """(mask, cache, key): the plan from the previous call's coefficients; the first call (or the first after
+        the cache was dropped) computes them synchronously."""
+        dy = getattr(self, "dy", self.dx)
+        key = key + (self.dt, self.dx, dy, self.num_steps, u.device)
+        cache = self.__dict__.setdefault("_kmax_cache", {})
+        old = cache.get(key)
+        if old is None:
+            cache.clear()
+            host, ev = F_.kappa_max_async(u, *args, flat, **kw)
+            ev.synchronize()
+            old = (host, ev, plan(host.tolist()))
+        elif old[1].query():
+            old = (old[0], old[1], plan(old[0].tolist()))
+        return old, cache, key
 
     def _diffuse(self, u, sweeps):
         args = (self.alpha_base, self.beta_base, self.alpha_time_coeff, self.beta_time_coeff)
         kw = dict(smooth3=self._smooth3, clamp_max=self._clamp_max, eps=self.stability_eps)
-        ck, sink = self.checkpoint_policy, None
-        if ck == "lagged":
-            if not (torch.is_grad_enabled() and (u.requires_grad or any(p.requires_grad for p in args))):
-                ck = 0
-            else:
-                cache = self.__dict__.setdefault("_kmax_cache", {})
-                key = (len(sweeps), sweeps[0].t, u.device)
-                old = cache.get(key)
-                if old is None:                            # first call only: wait for the coefficients
-                    host, ev = F_.kappa_max_async(u, *args, sweeps, **kw)
-                    ev.synchronize()
-                    old = (host, ev, F_.plan_checkpoints(host.tolist(), F_.CKPT_AMAX / 2))
-                elif old[1].query():
-                    old = (old[0], old[1], F_.plan_checkpoints(old[0].tolist(), F_.CKPT_AMAX / 2))
-                ck, sink = old[2], []
-                y = F_.adi_diffuse(u, *args, sweeps, checkpoints=ck, kmax_sink=sink, **kw)
-                cache[key] = (sink[0][0], sink[0][1], ck) if sink else old
-                return y
-        return F_.adi_diffuse(u, *args, sweeps, checkpoints=ck, **kw)
-
+        ck = self.checkpoint_policy
+        if not (torch.is_grad_enabled() and (u.requires_grad or any(p.requires_grad for p in args))):
+            ck = 0
+        if ck != "lagged":
+            return F_.adi_diffuse(u, *args, sweeps, checkpoints=ck, **kw)
+        old, cache, key = self._lagged_plan(("plain", len(sweeps), sweeps[0].t), u, args, kw, sweeps,
+                                            lambda km: F_.plan_checkpoints(km, F_.CKPT_AMAX / 2))
+        sink = []
+        y = F_.adi_diffuse(u, *args, sweeps, checkpoints=old[2], kmax_sink=sink, **kw)
+        cache[key] = (sink[0][0], sink[0][1], old[2]) if sink else old
+        return y
 
     def _run(self, u, steps, M=None, mode=None):
         """All steps of the layer.  One launch sequence holds at most PDE_MAX_SWEEPS sweeps: longer schedules
@@ -99,15 +116,15 @@ class _AdiBase(nn.Module):
         return u
 
     def _diffuse_mixed(self, u, steps, M, mode):
-        """All steps of a layer with a channel operator between them (functional.adi_diffuse_mixed), with
-        the same lagged choice of checkpoints as ``_diffuse`` (one step-local mask for every step)."""
+        """All steps of a layer with a channel operator between them (functional.adi_diffuse_mixed); checkpoints
+        as in ``_diffuse`` (one step-local mask for every step)."""
         args = (self.alpha_base, self.beta_base, self.alpha_time_coeff, self.beta_time_coeff)
         kw = dict(smooth3=self._smooth3, clamp_max=self._clamp_max, eps=self.stability_eps)
         ck = self.checkpoint_policy
+        if not (torch.is_grad_enabled() and (u.requires_grad or M.requires_grad or any(p.requires_grad for p in args))):
+            ck = 0
         if ck != "lagged":
             return F_.adi_diffuse_mixed(u, *args, M, steps, mode, checkpoints=ck, **kw)
-        if not (torch.is_grad_enabled() and (u.requires_grad or M.requires_grad or any(p.requires_grad for p in args))):
-            return F_.adi_diffuse_mixed(u, *args, M, steps, mode, checkpoints=0, **kw)
         sps = len(steps[0])
 
         def plan(km):
@@ -115,16 +132,8 @@ class _AdiBase(nn.Module):
             for k in range(len(steps)):
                 bits |= F_.plan_checkpoints(km[k * sps:(k + 1) * sps], F_.CKPT_AMAX / 2)
             return bits
-        cache = self.__dict__.setdefault("_kmax_cache", {})
-        key = ("mixed", len(steps), sps, steps[0][0].t, u.device)
-        old = cache.get(key)
-        if old is None:                                    # first call only: wait for the coefficients
-            flat = [s for st in steps for s in st]
-            host, ev = F_.kappa_max_async(u, *args, flat, **kw)
-            ev.synchronize()
-            old = (host, ev, plan(host.tolist()))
-        elif old[1].query():
-            old = (old[0], old[1], plan(old[0].tolist()))
+        old, cache, key = self._lagged_plan(("mixed", len(steps), sps, steps[0][0].t), u, args, kw,
+                                            [s for st in steps for s in st], plan)
         sink = []
         y = F_.adi_diffuse_mixed(u, *args, M, steps, mode, checkpoints=old[2], kmax_sink=sink, **kw)
         cache[key] = (sink[0][0], sink[0][1], old[2]) if sink else old

@@ -9,7 +9,9 @@
  *   - plain pointers and sizes only; all tensor pointers are DEVICE pointers
  *     (the caller owns every buffer), NCHW contiguous;
  *   - every call enqueues work on `stream` (a hipStream_t passed as void*) and
- *     returns immediately; no allocation, no synchronisation, no global state;
+ *     returns immediately; no allocation, no synchronisation.  Process-wide state is limited to
+ *     bookkeeping that never changes a result: one "dynamic-LDS attribute set" bit per (kernel,
+ *     device) behind a mutex, and the optional timing recorder of pde_timing_*;
  *   - return value: 0 on success, a negative PDE_E_* code otherwise (never throws).
  */
 #ifndef PDECNN_H
@@ -29,7 +31,7 @@ extern "C" {
 #define PDE_E_BADARG (-1)          /* null pointer, non-positive dim, bad enum */
 #define PDE_E_UNSUPPORTED_N (-2)   /* N not a multiple of 4 or > PDE_MAX_N */
 #define PDE_E_TOO_MANY_SWEEPS (-3)
-#define PDE_E_LAUNCH (-4)          /* hipLaunch failed; hipGetLastError has details */
+#define PDE_E_LAUNCH (-4)          /* hipLaunch failed; hipPeekAtLastError/hipGetLastError has details */
 #define PDE_E_WORKSPACE (-5)       /* workspace too small / misaligned */
 
 #define PDE_IO_F32 0
@@ -73,12 +75,18 @@ size_t pde_adi_backward_workspace_bytes(const PdeAdiDesc* d, int32_t num_checkpo
  * alpha_xxx / beta_xxx: (C,N,N) fp32.  u, y: (B,C,N,N) of io_dtype; y must not alias u.
  * kappa_max: NULL, or a device buffer of num_sweeps floats that receives the maximum
  * coefficient of every sweep (same values as pde_adi_kappa_max, at no extra launch).
+ * kappa_max_host: NULL, or PINNED host memory of num_sweeps floats: the maxima are copied there
+ * asynchronously right behind the factorisation kernel, i.e. BEFORE the sweep kernel is launched
+ * (needs kappa_max).  kappa_event: NULL, or a hipEvent_t the call records on `stream` behind that copy:
+ * the host can plan the backward's checkpoints from this call's own coefficients after a wait of
+ * microseconds, long before the forward has finished.
  * After the call the workspace holds the factorisation of every sweep; while it stays intact it
  * may be handed to pde_adi_backward as fwd_workspace to skip refactorising. */
 int pde_adi_forward(const PdeAdiDesc* d, const void* u, void* y,
                     const float* alpha_base, const float* beta_base,
                     const float* alpha_slope, const float* beta_slope,
-                    float* kappa_max, void* workspace, size_t workspace_bytes, void* stream);
+                    float* kappa_max, float* kappa_max_host, void* kappa_event,
+                    void* workspace, size_t workspace_bytes, void* stream);
 
 /* Exact reverse-mode derivative of pde_adi_forward (the reference gets it from autograd,
  * SURVEY.md §3d).  Inputs: gy = dL/dy, y = forward output.  Outputs: gu = dL/du and the
@@ -148,7 +156,8 @@ int pde_adi_mixed_forward(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t 
                           const void* u, void* states, const float* M,
                           const float* alpha_base, const float* beta_base,
                           const float* alpha_slope, const float* beta_slope,
-                          float* kappa_max, void* steps_workspace, size_t workspace_bytes, void* stream);
+                          float* kappa_max, float* kappa_max_host, void* kappa_event /* as in pde_adi_forward */,
+                          void* steps_workspace, size_t workspace_bytes, void* stream);
 size_t pde_adi_mixed_backward_workspace_bytes(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t num_checkpoints);
 int pde_adi_mixed_backward(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t mode,
                            const void* gy, const void* u, const void* states, const float* M,

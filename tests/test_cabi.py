@@ -48,12 +48,12 @@ def test_argument_validation_without_gpu():
     d = _lib.PdeAdiDesc()
     d.B, d.C, d.N, d.num_sweeps = 1, 1, 30, 3          # 30 is not a supported line length
     assert lib.pde_adi_forward_workspace_bytes(C.byref(d)) == 0
-    assert lib.pde_adi_forward(C.byref(d), None, None, None, None, None, None, None, None, 0, None) == -2
+    assert lib.pde_adi_forward(C.byref(d), None, None, None, None, None, None, None, None, None, None, 0, None) == -2
     d.N, d.num_sweeps = 32, _lib.PDE_MAX_SWEEPS + 1
-    assert lib.pde_adi_forward(C.byref(d), None, None, None, None, None, None, None, None, 0, None) == -3
+    assert lib.pde_adi_forward(C.byref(d), None, None, None, None, None, None, None, None, None, None, 0, None) == -3
     d.num_sweeps = 3
     assert lib.pde_adi_forward_workspace_bytes(C.byref(d)) > 0
-    assert lib.pde_adi_forward(C.byref(d), None, None, None, None, None, None, None, None, 0, None) == -1   # null pointers
+    assert lib.pde_adi_forward(C.byref(d), None, None, None, None, None, None, None, None, None, None, 0, None) == -1   # null pointers
     assert lib.pde_channel_mix_forward(0, 3, 16, 0, None, None, None, None) == -1
     assert lib.pde_explicit5_forward(1, 1, 8, 6, 0, None, None, None, 0.01, 1e-6, 0.15, 0.1, None, None) == -1
     assert lib.pde_version().startswith(b"pdecnn-hip")
