@@ -3,8 +3,10 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-N = 1 runs in-process; for N > 1 the driver launches this file under torch.distributed.run
-(one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
+N = 1 runs in-process.  For N > 1 the file runs as one rank per GPU over RCCL: either the driver launches it
+under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the environment), or — called plainly as
+``python bench.py --gpus N`` — it starts ``python -m torch.distributed.run --nproc-per-node N`` on itself as a
+CHILD process before anything touches the GPU and exits with the child's code.  Rank 0 prints ONE JSON line.
 
 Workload (BASELINE.json configs[1]): cifar10.EnhancedDiffusionLayer
 (size 32, channels 64, dt 1e-3, 10 Strang steps = 30 implicit sweeps), batch 512 per GPU, fp32,
@@ -13,13 +15,17 @@ forward + backward of the layer over one batch; with N > 1 the batch is sharded 
 and the layer's parameter gradients are all-reduced over RCCL every step.
 Primary line: channel mixing disabled (diffusion path only — SURVEY.md §8d declares it the
 primary configuration; the C=64 mixing product is a GEMM outside the stencil path).  The
-same workload WITH channel mixing is reported under "secondary".
+same workload WITH channel mixing is reported under "secondary", and the other BASELINE.json
+configurations (SURVEY §8d cfg1, cfg3 at C=1 and C=32, cfg4 bf16, cfg5) under "configs", each timed the same
+way (warm-up, K steps between synchronisations, max over ranks) with its algorithmic-bytes HBM fraction.
 """
 import argparse
 import contextlib
 import io
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -130,6 +136,56 @@ def cpu_baseline(C, N, steps, sample_B):
     return out
 
 
+def config_legs(dev, rank, world, dist_on, quick):
+    """The other BASELINE.json configurations, per-GPU batch fixed (weak scaling), each timed like
+    the headline: warm-up, K steps between barrier+synchronize, max over ranks, gradients all-reduced when N > 1.
+    bytes/element: 20 fp32, 10 bf16 (SURVEY §8d algorithmic bytes)."""
+    import cnn_with_pde_amd as P
+    legs = {}
+
+    def leg(name, layer, shape, dtype, bpe, steps, desc):
+        layer = layer.to(dev)
+        g = torch.Generator().manual_seed(4321 + rank)
+        u = torch.randn(*shape, generator=g).to(dtype).to(dev).requires_grad_(True)
+        gy = torch.randn(*shape, generator=g).to(dtype).to(dev)
+        flat = P.GradBucket(layer.parameters()) if dist_on else None
+        dt = timed(layer, u, gy, steps, 3, dist_on, flat)
+        ms = dt / steps * 1e3
+        gbs = u.numel() * bpe / (dt / steps) / 1e9            # per GPU
+        if rank == 0:
+            legs[name] = {"workload": desc, "per_gpu_shape": list(shape), "dtype": str(dtype).replace("torch.", ""),
+                          "steps": steps, "ms_per_step": ms, "value": shape[0] * world / (dt / steps) / 1e6,
+                          "unit": "Msamples/s", "algorithmic_GBps_per_gpu": gbs, "frac": gbs / HBM_PEAK_GBS,
+                          "bytes_per_element": bpe}
+        del layer, u, gy
+        torch.cuda.empty_cache()
+
+    k = 5 if quick else 20
+    with contextlib.redirect_stdout(io.StringIO()):
+        mn = P.MnistDiffusionLayer()
+        fa = P.FashionDiffusionLayer()
+        c32 = P.SvhnDiffusionLayer(28, 32, dt=0.3, num_steps=4)
+        c4 = P.SvhnDiffusionLayer(32, 128, num_steps=20)
+        c5 = P.ImprovedDiffusionLayer(64, 64)
+    gp = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        # cfg3 at 32 channels: fashion semantics broadcast per channel = the SVHN layer with coupling I and the
+        # skip weight at -40 (sigmoid ~ 4e-18: the output is the diffused branch) — SURVEY §8d
+        c32.alpha_base.fill_(1.8); c32.beta_base.fill_(1.8); c32.alpha_time_coeff.zero_(); c32.beta_time_coeff.zero_()
+        c32.channel_coupling.copy_(torch.eye(32)); c32.skip_weight.fill_(-40.0)
+        c4.channel_coupling.copy_(torch.eye(128) + 0.01 * torch.randn(128, 128, generator=gp))
+    leg("cfg1", mn, (64, 1, 28, 28), torch.float32, 20, k, "mnist_test.DiffusionLayer(), batch 64 (BASELINE configs[0])")
+    leg("cfg3_c1", fa, (4096, 1, 28, 28), torch.float32, 20, k,
+        "fashion_mnist.DiffusionLayer() literal C=1, batch 4096/GPU (BASELINE configs[2])")
+    leg("cfg3_c32", c32, (512, 32, 28, 28), torch.float32, 20, k,
+        "SVHN.DiffusionLayer(28,32,dt=0.3,num_steps=4), fashion coefficients, coupling each step, batch 512/GPU")
+    leg("cfg4_bf16", c4, (512, 128, 32, 32), torch.bfloat16, 10, max(3, k // 4),
+        "SVHN.DiffusionLayer(32,128,num_steps=20) bf16 tensors, 60 sweeps + 20 couplings + skip, batch 512/GPU (BASELINE configs[3])")
+    leg("cfg5", c5, (256, 64, 64, 64), torch.float32, 20, k,
+        "tiny_imagenet.ImprovedDiffusionLayer(64,64) explicit 5-point step, batch 256/GPU (BASELINE configs[4])")
+    return legs
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -141,6 +197,7 @@ def main():
     ap.add_argument("--num-steps", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the per-config legs (cfg1, cfg3, cfg4, cfg5)")
     ap.add_argument("--cpu-sample", type=int, default=160, help="upper bound of the CPU baseline sample (samples)")
     a = ap.parse_args()
 
@@ -151,16 +208,25 @@ def main():
     if a.gpus != world and dist_on:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if a.gpus > 1 and not dist_on:
-        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nnodes=1 "
-                         "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        # plain `python bench.py --gpus N`: start the N ranks ourselves, as a child process, BEFORE any GPU call
+        # in this one (never a re-exec), and hand its stdout (rank 0's one JSON line) and exit code through
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    rccl_ws = 1
     if dist_on:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
+        rccl_ws = dist.get_world_size()
 
     import cnn_with_pde_amd as P
     B, C, N, steps = a.batch, a.channels, a.size, a.num_steps
@@ -198,13 +264,14 @@ def main():
 
     out = None
     if rank == 0:
-        pmc, valu = None, None
+        pmc, valu, pmc_src = None, None, None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.isfile(pmc_path) and (B, C, N, steps) == (512, 64, 32, 10):     # counters were taken on this workload
             with open(pmc_path) as f:
                 pj = json.load(f)
             pmc = pj.get("adi_bwd_kernel_bytes_per_launch")
             valu = pj.get("sq_insts_valu_per_launch")
+            pmc_src = {"file": "profiles/pmc_traffic.json", "taken_at_commit": pj.get("commit"), "passes": pj.get("source")}
         ach = elems * BYTES_PER_ELEM["bwd"] / (bwd_ms * 1e-3) / 1e9
         out = {
             "metric": "PDE-layer fwd+bwd Msamples/s", "value": samples_s / 1e6, "unit": "Msamples/s",
@@ -214,9 +281,11 @@ def main():
                                    f"fwd+bwd, {3 * steps} implicit sweeps, batch {B}/GPU, channel mixing disabled "
                                    "(BASELINE configs[1], SURVEY §8d cfg2 primary)",
                        "global_batch": B * world, "parallelism": f"dp{world}",
-                       "grad_allreduce_bytes": (flat.nbytes() if flat is not None else 0)},
+                       "grad_allreduce_bytes": (flat.nbytes() if flat is not None else 0),
+                       "rccl_world_size": rccl_ws},
             "roofline": {"bound": "hbm", "kernel": "adi_bwd_kernel", "achieved": ach, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc, "copy_ceiling_measured": copy_gbs,
+                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc, "traffic_source": pmc_src,
+                         "copy_ceiling_measured": copy_gbs,
                          "algorithmic_bytes_per_launch": elems * BYTES_PER_ELEM["bwd"], "avg_launch_ms": bwd_ms},
             "roofline_fwd": {"bound": "hbm", "kernel": "adi_fwd_kernel",
                              "achieved": elems * BYTES_PER_ELEM["fwd"] / (fwd_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
@@ -245,6 +314,13 @@ def main():
                                 "value": B * world * k2 / dt2 / 1e6, "unit": "Msamples/s",
                                 "ms_per_step": dt2 / k2 * 1e3}
         del layer2
+
+    if not a.no_configs:
+        del u, gy, layer
+        torch.cuda.empty_cache()
+        legs = config_legs(dev, rank, world, dist_on, quick=a.steps < 20)
+        if rank == 0:
+            out["configs"] = legs
 
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:

@@ -183,12 +183,18 @@ def _implicit_sweep(u: torch.Tensor, theta: torch.Tensor, axis: int, delta: floa
     return x
 
 
-def adi_forward(u: torch.Tensor, params: Dict[str, torch.Tensor], spec: AdiSpec) -> torch.Tensor:
+def adi_forward(u: torch.Tensor, params: Dict[str, torch.Tensor], spec: AdiSpec, state_cast=None) -> torch.Tensor:
     """Forward of a K1 layer.  ``u`` is (B,C,H,W); parameters are (C,H,W)
     (``(H,W)`` is accepted for the single-channel classes) plus the optional
     ``channel_mixing`` / ``channel_coupling`` (C,C) and scalar ``skip_weight``.
     Differentiable through torch autograd, any float dtype.
+
+    ``state_cast`` (tests of reduced-precision tensor I/O only; not part of the reference): a function applied
+    to the state after each channel operator, after the sweeps of each time step and to the result — the points
+    at which an implementation with bf16 tensors and fp32 arithmetic rounds, e.g.
+    ``lambda t: t.bfloat16().float()`` (autograd then rounds the gradient at the same points).
     """
+    cast = state_cast if state_cast is not None else (lambda t: t)
     B, C, H, W = u.shape
 
     def chw(p):
@@ -202,20 +208,22 @@ def adi_forward(u: torch.Tensor, params: Dict[str, torch.Tensor], spec: AdiSpec)
     for k in range(spec.num_steps):
         if spec.mix == "pre":
             # cifar10.py:65-72  out[b,i,p] = sum_j M[i,j] u[b,j,p]
-            u = torch.matmul(params["channel_mixing"], u.reshape(B, C, H * W)).view(B, C, H, W)
+            u = cast(torch.matmul(params["channel_mixing"], u.reshape(B, C, H * W)).view(B, C, H, W))
         for axis, delta, t in sched[k * per_step:(k + 1) * per_step]:
             if axis == 0:
                 u = _implicit_sweep(u, coefficient_at(ab, asl, t, spec), 0, delta, spec.dx, spec)
             else:
                 u = _implicit_sweep(u, coefficient_at(bb, bsl, t, spec), 1, delta, spec.dy, spec)
+        if spec.mix != "none":
+            u = cast(u)
         if spec.mix == "post":
             # SVHN.py:78-86  (B*H*W, C) @ K^T
             flat = u.permute(0, 2, 3, 1).contiguous().view(B * H * W, C)
-            u = torch.matmul(flat, params["channel_coupling"].t()).view(B, H, W, C).permute(0, 3, 1, 2).contiguous()
+            u = cast(torch.matmul(flat, params["channel_coupling"].t()).view(B, H, W, C).permute(0, 3, 1, 2).contiguous())
     if spec.skip:
         s = torch.sigmoid(params["skip_weight"])
         u = s * u0 + (1 - s) * u                      # SVHN.py:74
-    return u
+    return cast(u)
 
 
 def adi_init_params(spec: AdiSpec, variant: str, dtype=torch.float32, gen: Optional[torch.Generator] = None
