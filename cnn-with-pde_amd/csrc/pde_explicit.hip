@@ -3,7 +3,12 @@
 // explicit5: tiny_imagenet.py:34-72, one relaxed step
 //     a_c = clamp(alpha_base_c, eps, max_coeff);  v = s_c u
 //     out = u + relax*(v + a_c*dt*Lap0(v) - u)            Lap0: zero ghost cells (conv2d padding=1)
-//   HBM-bound: 4 B read + 4 B written per element; neighbours come from L1/L2.
+//   HBM-bound: 4 B read + 4 B written per element.  Planes of 64x64, 32x32 and 16x16 take the wave-per-plane
+//   kernels below: a wave keeps its whole plane in registers (lane = (row group, 4-column group), R consecutive
+//   rows of one float4 each), so every element is loaded from memory exactly once; east/west neighbours come
+//   from the neighbouring lane by DPP wave shifts, north/south from the lane's own registers, the two halo rows
+//   of a row group from the lanes W/4 away (__shfl); num_steps > 1 stay in registers between the steps.  Other
+//   plane sizes take the generic kernel (neighbours through L1/L2), one launch per step.
 //   Backward (Lap0 is self-adjoint):
 //     gu   = (1-relax) g + relax*s_c*(g + a_c dt Lap0 g)
 //     gs_c = relax * sum (g + a_c dt Lap0 g) u
@@ -37,6 +42,7 @@ template <> struct V4<float> {
         const f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p));
         return make_float4(v.x, v.y, v.z, v.w);
     }
+    __device__ static __forceinline__ float4 round(float4 v) { return v; }
 };
 template <> struct V4<bf16e> {
     __device__ static __forceinline__ float4 ld(const bf16e* p) {
@@ -49,6 +55,9 @@ template <> struct V4<bf16e> {
     }
     __device__ static __forceinline__ float ld1(const bf16e* p) { return bf2f(p->v); }
     __device__ static __forceinline__ float4 ld_once(const bf16e* p) { return ld(p); }
+    __device__ static __forceinline__ float4 round(float4 v) {
+        return make_float4(bf2f(f2bf(v.x)), bf2f(f2bf(v.y)), bf2f(f2bf(v.z)), bf2f(f2bf(v.w)));
+    }
 };
 
 // 5-point Laplacian with zero ghost cells of 4 consecutive columns (h, w0..w0+3) of one plane
@@ -107,7 +116,7 @@ __global__ __launch_bounds__(256) void explicit5_bwd_kernel(const IO* __restrict
                                                             const float* __restrict__ alpha,
                                                             const float* __restrict__ scale, IO* __restrict__ gu,
                                                             float* __restrict__ part, int C, int H, int W, float dt,
-                                                            float eps, float maxc, float relax) {
+                                                            float eps, float maxc, float relax, int accumulate) {
     __shared__ float sh[4];
     const int pc = blockIdx.x;
     const int c = pc % C;
@@ -134,7 +143,10 @@ __global__ __launch_bounds__(256) void explicit5_bwd_kernel(const IO* __restrict
     }
     const float s1 = block_sum_256(p1, sh);
     const float s2 = block_sum_256(p2, sh);
-    if (threadIdx.x == 0) { part[2 * (size_t)pc] = s1; part[2 * (size_t)pc + 1] = s2; }
+    if (threadIdx.x == 0) {
+        part[2 * (size_t)pc] = accumulate ? part[2 * (size_t)pc] + s1 : s1;
+        part[2 * (size_t)pc + 1] = accumulate ? part[2 * (size_t)pc + 1] + s2 : s2;
+    }
 }
 
 // one workgroup per channel: 256 threads add the per-plane partial sums of their samples, then a
@@ -159,6 +171,154 @@ __global__ __launch_bounds__(256) void explicit5_pgrad_kernel(const float* __res
         gs[c] = relax * (s1 + a * s2);
         ga[c] = (ab >= eps && ab <= maxc) ? relax * dt * scale[c] * s2 : 0.f;
     }
+}
+
+
+// ---------------------------------------------------------------------------------------
+// wave-per-plane kernels: the plane lives in registers for the whole call
+// ---------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_shift(float v) {     // 0 is shifted in at the ends of the wave
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+constexpr int kWaveShl1 = 0x130;    // lane i <- lane i+1
+constexpr int kWaveShr1 = 0x138;    // lane i <- lane i-1
+__device__ __forceinline__ float4 shfl_up4(float4 v, int d) {
+    return make_float4(__shfl_up(v.x, d, 64), __shfl_up(v.y, d, 64), __shfl_up(v.z, d, 64), __shfl_up(v.w, d, 64));
+}
+__device__ __forceinline__ float4 shfl_down4(float4 v, int d) {
+    return make_float4(__shfl_down(v.x, d, 64), __shfl_down(v.y, d, 64), __shfl_down(v.z, d, 64), __shfl_down(v.w, d, 64));
+}
+
+// Lap0 of the lane's R rows (zero ghost cells): same operation order as lap0_4
+template <int R, int W4>
+__device__ __forceinline__ void lap0_rows(const float4 (&c)[R], float4 (&lp)[R], int cg, int rg) {
+    constexpr int RG = 64 / W4;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 top = shfl_up4(c[R - 1], W4), bot = shfl_down4(c[0], W4);
+    if (rg == 0) top = z;
+    if (rg == RG - 1) bot = z;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const float4 n = (i > 0) ? c[i - 1] : top;
+        const float4 s = (i < R - 1) ? c[i + 1] : bot;
+        float l = dpp_shift<kWaveShr1>(c[i].w), r = dpp_shift<kWaveShl1>(c[i].x);
+        if (cg == 0) l = 0.f;
+        if (cg == W4 - 1) r = 0.f;
+        lp[i].x = n.x + s.x + l + c[i].y - 4.f * c[i].x;
+        lp[i].y = n.y + s.y + c[i].x + c[i].z - 4.f * c[i].y;
+        lp[i].z = n.z + s.z + c[i].y + c[i].w - 4.f * c[i].z;
+        lp[i].w = n.w + s.w + c[i].z + r - 4.f * c[i].w;
+    }
+}
+
+template <typename IO, int R, int W4>
+__global__ __launch_bounds__(256) void explicit5_fwd_wave(const IO* __restrict__ u, const float* __restrict__ alpha,
+                                                          const float* __restrict__ scale, IO* __restrict__ out,
+                                                          IO* __restrict__ states, int nplanes, int C, int num_steps,
+                                                          float dt, float eps, float maxc, float relax) {
+    constexpr int W = 4 * W4, H = R * (64 / W4);
+    const int lane = threadIdx.x & 63;
+    const int pc = blockIdx.x * 4 + (threadIdx.x >> 6);          // one wave per plane
+    if (pc >= nplanes) return;
+    const int c = pc % C;
+    const float a = fminf(fmaxf(alpha[c], eps), maxc) * dt;
+    const float s = scale[c];
+    const int cg = lane % W4, rg = lane / W4;
+    const size_t off = (size_t)pc * H * W + (size_t)(rg * R) * W + 4 * cg;
+    float4 cur[R], lp[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) cur[i] = V4<IO>::ld_once(u + off + (size_t)i * W);
+    for (int step = 0; step < num_steps; ++step) {
+        lap0_rows<R, W4>(cur, lp, cg, rg);
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            // v = s u; new = v + a*(s*lap); out = u + relax*(new - u)      tiny_imagenet.py:43-49
+            { const float v = s * cur[i].x; const float nw = v + a * (s * lp[i].x); cur[i].x = cur[i].x + relax * (nw - cur[i].x); }
+            { const float v = s * cur[i].y; const float nw = v + a * (s * lp[i].y); cur[i].y = cur[i].y + relax * (nw - cur[i].y); }
+            { const float v = s * cur[i].z; const float nw = v + a * (s * lp[i].z); cur[i].z = cur[i].z + relax * (nw - cur[i].z); }
+            { const float v = s * cur[i].w; const float nw = v + a * (s * lp[i].w); cur[i].w = cur[i].w + relax * (nw - cur[i].w); }
+        }
+        if (step + 1 < num_steps && states != nullptr) {          // inputs of the later steps, for the backward
+            IO* sp = states + (size_t)step * nplanes * H * W;
+#pragma unroll
+            for (int i = 0; i < R; ++i) V4<IO>::st(sp + off + (size_t)i * W, cur[i]);
+            if (sizeof(IO) < 4) {                                 // later steps continue from the ROUNDED state,
+#pragma unroll
+                for (int i = 0; i < R; ++i) cur[i] = V4<IO>::round(cur[i]);   // as the backward will read it
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) V4<IO>::st(out + off + (size_t)i * W, cur[i]);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// backward of num_steps steps: g walks back through the steps in registers; u_{k-1} (the input of step k) is the
+// layer input for k = 1 and states[k-2] otherwise
+template <typename IO, int R, int W4>
+__global__ __launch_bounds__(256) void explicit5_bwd_wave(const IO* __restrict__ u, const IO* __restrict__ states,
+                                                          const IO* __restrict__ g, const float* __restrict__ alpha,
+                                                          const float* __restrict__ scale, IO* __restrict__ gu,
+                                                          float* __restrict__ part, int nplanes, int C, int num_steps,
+                                                          float dt, float eps, float maxc, float relax) {
+    constexpr int W = 4 * W4, H = R * (64 / W4);
+    const int lane = threadIdx.x & 63;
+    const int pc = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pc >= nplanes) return;
+    const int c = pc % C;
+    const float a = fminf(fmaxf(alpha[c], eps), maxc) * dt;
+    const float s = scale[c];
+    const int cg = lane % W4, rg = lane / W4;
+    const size_t off = (size_t)pc * H * W + (size_t)(rg * R) * W + 4 * cg;
+    float4 cg4[R], lg[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) cg4[i] = V4<IO>::ld_once(g + off + (size_t)i * W);
+    float p1 = 0.f, p2 = 0.f;                                     // sum g*u, sum Lap0(g)*u over all steps
+    for (int step = num_steps; step >= 1; --step) {
+        const IO* up = (step == 1) ? u : states + (size_t)(step - 2) * nplanes * H * W;
+        lap0_rows<R, W4>(cg4, lg, cg, rg);
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const float4 cu = V4<IO>::ld_once(up + off + (size_t)i * W);
+            p1 += cg4[i].x * cu.x + cg4[i].y * cu.y + cg4[i].z * cu.z + cg4[i].w * cu.w;
+            p2 += lg[i].x * cu.x + lg[i].y * cu.y + lg[i].z * cu.z + lg[i].w * cu.w;
+            cg4[i].x = (1.f - relax) * cg4[i].x + relax * s * (cg4[i].x + a * lg[i].x);
+            cg4[i].y = (1.f - relax) * cg4[i].y + relax * s * (cg4[i].y + a * lg[i].y);
+            cg4[i].z = (1.f - relax) * cg4[i].z + relax * s * (cg4[i].z + a * lg[i].z);
+            cg4[i].w = (1.f - relax) * cg4[i].w + relax * s * (cg4[i].w + a * lg[i].w);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) V4<IO>::st(gu + off + (size_t)i * W, cg4[i]);
+    p1 = wave_sum(p1);
+    p2 = wave_sum(p2);
+    if (lane == 0) { part[2 * (size_t)pc] = p1; part[2 * (size_t)pc + 1] = p2; }
+}
+
+// which plane sizes the wave-per-plane kernels cover
+bool wave_plane_ok(int H, int W) { return (H == 64 && W == 64) || (H == 32 && W == 32) || (H == 16 && W == 16); }
+
+template <typename IO>
+void launch_fwd_wave(int H, const IO* u, const float* alpha, const float* scale, IO* out, IO* states, int nplanes, int C,
+                     int num_steps, float dt, float eps, float maxc, float relax, hipStream_t st) {
+    const dim3 grid((nplanes + 3) / 4), block(256);
+    if (H == 64) hipLaunchKernelGGL((explicit5_fwd_wave<IO, 16, 16>), grid, block, 0, st, u, alpha, scale, out, states, nplanes, C, num_steps, dt, eps, maxc, relax);
+    else if (H == 32) hipLaunchKernelGGL((explicit5_fwd_wave<IO, 4, 8>), grid, block, 0, st, u, alpha, scale, out, states, nplanes, C, num_steps, dt, eps, maxc, relax);
+    else hipLaunchKernelGGL((explicit5_fwd_wave<IO, 1, 4>), grid, block, 0, st, u, alpha, scale, out, states, nplanes, C, num_steps, dt, eps, maxc, relax);
+}
+template <typename IO>
+void launch_bwd_wave(int H, const IO* u, const IO* states, const IO* g, const float* alpha, const float* scale, IO* gu,
+                     float* part, int nplanes, int C, int num_steps, float dt, float eps, float maxc, float relax,
+                     hipStream_t st) {
+    const dim3 grid((nplanes + 3) / 4), block(256);
+    if (H == 64) hipLaunchKernelGGL((explicit5_bwd_wave<IO, 16, 16>), grid, block, 0, st, u, states, g, alpha, scale, gu, part, nplanes, C, num_steps, dt, eps, maxc, relax);
+    else if (H == 32) hipLaunchKernelGGL((explicit5_bwd_wave<IO, 4, 8>), grid, block, 0, st, u, states, g, alpha, scale, gu, part, nplanes, C, num_steps, dt, eps, maxc, relax);
+    else hipLaunchKernelGGL((explicit5_bwd_wave<IO, 1, 4>), grid, block, 0, st, u, states, g, alpha, scale, gu, part, nplanes, C, num_steps, dt, eps, maxc, relax);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -340,46 +500,84 @@ extern "C" {
 
 int pde_explicit5_forward(int32_t B, int32_t C, int32_t H, int32_t W, int32_t io_dtype, const void* u,
                           const float* alpha_base, const float* channel_scaling, float dt, float eps, float max_coeff,
-                          float relax, void* out, void* stream) {
-    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || (W % 4) != 0 || !u || !alpha_base || !channel_scaling || !out)
+                          float relax, int32_t num_steps, void* states, void* out, void* stream) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || (W % 4) != 0 || num_steps < 1 || !u || !alpha_base || !channel_scaling || !out)
         return PDE_E_BADARG;
+    if (io_dtype != PDE_IO_F32 && io_dtype != PDE_IO_BF16) return PDE_E_BADARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (io_dtype == PDE_IO_F32)
-        hipLaunchKernelGGL((explicit5_fwd_kernel<float>), dim3(B * C), dim3(256), 0, st, (const float*)u, alpha_base,
-                           channel_scaling, (float*)out, C, H, W, dt, eps, max_coeff, relax);
-    else if (io_dtype == PDE_IO_BF16)
-        hipLaunchKernelGGL((explicit5_fwd_kernel<bf16e>), dim3(B * C), dim3(256), 0, st, (const bf16e*)u, alpha_base,
-                           channel_scaling, (bf16e*)out, C, H, W, dt, eps, max_coeff, relax);
-    else
-        return PDE_E_BADARG;
+    const int nplanes = B * C;
+    if (wave_plane_ok(H, W)) {                             // the plane stays in registers over all steps
+        if (io_dtype == PDE_IO_F32)
+            launch_fwd_wave<float>(H, (const float*)u, alpha_base, channel_scaling, (float*)out, (float*)states, nplanes, C,
+                                   num_steps, dt, eps, max_coeff, relax, st);
+        else
+            launch_fwd_wave<bf16e>(H, (const bf16e*)u, alpha_base, channel_scaling, (bf16e*)out, (bf16e*)states, nplanes, C,
+                                   num_steps, dt, eps, max_coeff, relax, st);
+        return check_launch();
+    }
+    if (num_steps > 1 && !states) return PDE_E_BADARG;     // generic sizes: one launch per step through `states`
+    const size_t tb = (size_t)nplanes * H * W * (io_dtype == PDE_IO_BF16 ? 2 : 4);
+    for (int k = 0; k < num_steps; ++k) {
+        const void* src = (k == 0) ? u : static_cast<const char*>(states) + (size_t)(k - 1) * tb;
+        void* dst = (k == num_steps - 1) ? out : static_cast<char*>(states) + (size_t)k * tb;
+        if (io_dtype == PDE_IO_F32)
+            hipLaunchKernelGGL((explicit5_fwd_kernel<float>), dim3(nplanes), dim3(256), 0, st, (const float*)src, alpha_base,
+                               channel_scaling, (float*)dst, C, H, W, dt, eps, max_coeff, relax);
+        else
+            hipLaunchKernelGGL((explicit5_fwd_kernel<bf16e>), dim3(nplanes), dim3(256), 0, st, (const bf16e*)src, alpha_base,
+                               channel_scaling, (bf16e*)dst, C, H, W, dt, eps, max_coeff, relax);
+    }
     return check_launch();
 }
 
-size_t pde_explicit5_backward_workspace_bytes(int32_t B, int32_t C, int32_t H, int32_t W) {
-    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
-    return align256((size_t)B * C * 2 * sizeof(float));
+size_t pde_explicit5_backward_workspace_bytes(int32_t B, int32_t C, int32_t H, int32_t W, int32_t io_dtype,
+                                              int32_t num_steps) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || num_steps < 1) return 0;
+    size_t b = align256((size_t)B * C * 2 * sizeof(float));
+    if (num_steps > 1 && !wave_plane_ok(H, W))             // generic sizes: two gradient buffers to ping-pong through
+        b += 2 * align256((size_t)B * C * H * W * (io_dtype == PDE_IO_BF16 ? 2 : 4));
+    return b;
 }
 
 int pde_explicit5_backward(int32_t B, int32_t C, int32_t H, int32_t W, int32_t io_dtype, const void* u,
-                           const void* gout, const float* alpha_base, const float* channel_scaling, float dt,
-                           float eps, float max_coeff, float relax, void* gu, float* g_alpha_base,
-                           float* g_channel_scaling, void* workspace, size_t workspace_bytes, void* stream) {
-    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || (W % 4) != 0 || !u || !gout || !alpha_base || !channel_scaling ||
-        !gu || !g_alpha_base || !g_channel_scaling || !workspace)
+                           const void* states, const void* gout, const float* alpha_base, const float* channel_scaling,
+                           float dt, float eps, float max_coeff, float relax, int32_t num_steps, void* gu,
+                           float* g_alpha_base, float* g_channel_scaling, void* workspace, size_t workspace_bytes,
+                           void* stream) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || (W % 4) != 0 || num_steps < 1 || !u || !gout || !alpha_base ||
+        !channel_scaling || !gu || !g_alpha_base || !g_channel_scaling || !workspace || (num_steps > 1 && !states))
         return PDE_E_BADARG;
-    if (workspace_bytes < pde_explicit5_backward_workspace_bytes(B, C, H, W)) return PDE_E_WORKSPACE;
+    if (io_dtype != PDE_IO_F32 && io_dtype != PDE_IO_BF16) return PDE_E_BADARG;
+    if (workspace_bytes < pde_explicit5_backward_workspace_bytes(B, C, H, W, io_dtype, num_steps)) return PDE_E_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* part = static_cast<float*>(workspace);
-    if (io_dtype == PDE_IO_F32)
-        hipLaunchKernelGGL((explicit5_bwd_kernel<float>), dim3(B * C), dim3(256), 0, st, (const float*)u,
-                           (const float*)gout, alpha_base, channel_scaling, (float*)gu, part, C, H, W, dt, eps,
-                           max_coeff, relax);
-    else if (io_dtype == PDE_IO_BF16)
-        hipLaunchKernelGGL((explicit5_bwd_kernel<bf16e>), dim3(B * C), dim3(256), 0, st, (const bf16e*)u,
-                           (const bf16e*)gout, alpha_base, channel_scaling, (bf16e*)gu, part, C, H, W, dt, eps,
-                           max_coeff, relax);
-    else
-        return PDE_E_BADARG;
+    const int nplanes = B * C;
+    if (wave_plane_ok(H, W)) {
+        if (io_dtype == PDE_IO_F32)
+            launch_bwd_wave<float>(H, (const float*)u, (const float*)states, (const float*)gout, alpha_base, channel_scaling,
+                                   (float*)gu, part, nplanes, C, num_steps, dt, eps, max_coeff, relax, st);
+        else
+            launch_bwd_wave<bf16e>(H, (const bf16e*)u, (const bf16e*)states, (const bf16e*)gout, alpha_base, channel_scaling,
+                                   (bf16e*)gu, part, nplanes, C, num_steps, dt, eps, max_coeff, relax, st);
+    } else {
+        const size_t tb = (size_t)nplanes * H * W * (io_dtype == PDE_IO_BF16 ? 2 : 4);
+        char* buf0 = static_cast<char*>(workspace) + align256((size_t)nplanes * 2 * sizeof(float));
+        char* buf1 = buf0 + align256(tb);
+        const void* gin = gout;
+        for (int k = num_steps; k >= 1; --k) {
+            const void* up = (k == 1) ? u : static_cast<const char*>(states) + (size_t)(k - 2) * tb;
+            void* gdst = (k == 1) ? gu : (gin == buf0 ? buf1 : buf0);
+            if (io_dtype == PDE_IO_F32)
+                hipLaunchKernelGGL((explicit5_bwd_kernel<float>), dim3(nplanes), dim3(256), 0, st, (const float*)up,
+                                   (const float*)gin, alpha_base, channel_scaling, (float*)gdst, part, C, H, W, dt, eps,
+                                   max_coeff, relax, k == num_steps ? 0 : 1);
+            else
+                hipLaunchKernelGGL((explicit5_bwd_kernel<bf16e>), dim3(nplanes), dim3(256), 0, st, (const bf16e*)up,
+                                   (const bf16e*)gin, alpha_base, channel_scaling, (bf16e*)gdst, part, C, H, W, dt, eps,
+                                   max_coeff, relax, k == num_steps ? 0 : 1);
+            gin = gdst;
+        }
+    }
     hipLaunchKernelGGL(explicit5_pgrad_kernel, dim3(C), dim3(256), 0, st, part, alpha_base, channel_scaling,
                        g_alpha_base, g_channel_scaling, B, C, dt, eps, max_coeff, relax);
     return check_launch();

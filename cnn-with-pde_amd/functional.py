@@ -397,7 +397,7 @@ def channel_mix(u, M):
 # --------------------------------------------------------------------------- explicit layers
 class _Explicit5Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, u, alpha_base, channel_scaling, dt, eps, max_coeff, relax):
+    def forward(ctx, u, alpha_base, channel_scaling, dt, eps, max_coeff, relax, num_steps):
         lib = L.load()
         _require_cuda(u, alpha_base, channel_scaling)
         if u.dtype not in (torch.float32, torch.bfloat16):
@@ -407,35 +407,41 @@ class _Explicit5Fn(torch.autograd.Function):
         a = alpha_base.detach().to(torch.float32).contiguous()
         s = channel_scaling.detach().to(torch.float32).contiguous()
         out = torch.empty_like(u)
+        need_grad = any(ctx.needs_input_grad[:3])
+        fused = (H, W) in ((64, 64), (32, 32), (16, 16))         # planes that stay in registers over all steps
+        # inputs of steps 2..num_steps: what the backward reads (and what chains the steps for generic plane sizes)
+        states = torch.empty((num_steps - 1,) + tuple(u.shape), dtype=u.dtype, device=u.device) \
+            if num_steps > 1 and (need_grad or not fused) else None
         with torch.cuda.device(u.device):
             L.check(lib.pde_explicit5_forward(B, Cc, H, W, _io_dtype(u), _ptr(u), _ptr(a), _ptr(s), dt, eps, max_coeff,
-                                              relax, _ptr(out), _stream()), "pde_explicit5_forward")
-        ctx.save_for_backward(u, a, s)
-        ctx.cfg = (dt, eps, max_coeff, relax)
+                                              relax, num_steps, _ptr(states), _ptr(out), _stream()), "pde_explicit5_forward")
+        ctx.save_for_backward(u, states if need_grad else None, a, s)
+        ctx.cfg = (dt, eps, max_coeff, relax, num_steps)
         return out
 
     @staticmethod
     def backward(ctx, gout):
         lib = L.load()
-        u, a, s = ctx.saved_tensors
-        dt, eps, max_coeff, relax = ctx.cfg
+        u, states, a, s = ctx.saved_tensors
+        dt, eps, max_coeff, relax, num_steps = ctx.cfg
         B, Cc, H, W = u.shape
         gout = gout.to(u.dtype).contiguous()
         gu = torch.empty_like(u)
         ga, gs = torch.empty_like(a), torch.empty_like(s)
-        ws = _workspace(lib.pde_explicit5_backward_workspace_bytes(B, Cc, H, W), u.device)
+        ws = _workspace(lib.pde_explicit5_backward_workspace_bytes(B, Cc, H, W, _io_dtype(u), num_steps), u.device)
         with torch.cuda.device(u.device):
-            L.check(lib.pde_explicit5_backward(B, Cc, H, W, _io_dtype(u), _ptr(u), _ptr(gout), _ptr(a), _ptr(s), dt, eps,
-                                               max_coeff, relax, _ptr(gu), _ptr(ga), _ptr(gs), _ptr(ws), ws.numel(),
-                                               _stream()), "pde_explicit5_backward")
-        return gu, ga, gs, None, None, None, None
+            L.check(lib.pde_explicit5_backward(B, Cc, H, W, _io_dtype(u), _ptr(u), _ptr(states), _ptr(gout), _ptr(a), _ptr(s),
+                                               dt, eps, max_coeff, relax, num_steps, _ptr(gu), _ptr(ga), _ptr(gs), _ptr(ws),
+                                               ws.numel(), _stream()), "pde_explicit5_backward")
+        return gu, ga, gs, None, None, None, None, None
 
 
-def explicit5_step(u, alpha_base, channel_scaling, dt=0.01, eps=1e-6, max_coeff=0.15, relax=0.1):
-    """One relaxed explicit 5-point step — tiny_imagenet.py:38-49,53-72."""
-    if u.shape[0] == 0:
+def explicit5_step(u, alpha_base, channel_scaling, dt=0.01, eps=1e-6, max_coeff=0.15, relax=0.1, num_steps=1):
+    """``num_steps`` relaxed explicit 5-point steps in one call — tiny_imagenet.py:38-49,53-72."""
+    if u.shape[0] == 0 or num_steps < 1:
         return _empty_passthrough(u, alpha_base, channel_scaling)
-    return _Explicit5Fn.apply(u, alpha_base, channel_scaling, float(dt), float(eps), float(max_coeff), float(relax))
+    return _Explicit5Fn.apply(u, alpha_base, channel_scaling, float(dt), float(eps), float(max_coeff), float(relax),
+                              int(num_steps))
 
 
 class _JacobiFn(torch.autograd.Function):

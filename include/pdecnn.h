@@ -203,20 +203,24 @@ int pde_skip_blend_backward(int64_t n, int32_t io_dtype, const void* g, const vo
 
 /* ---- K2: explicit 5-point layers --------------------------- */
 
-/* tiny_imagenet.py:34-72, one relaxed explicit step:
+/* tiny_imagenet.py:34-72: `num_steps` relaxed explicit steps (the reference's loop :44-49), each
  *   a_c = clamp(alpha_base_c, eps, max_coeff);  v = s_c u;
- *   out = u + relax*(v + a_c*dt*Lap0(v) - u)      (Lap0: zero ghost cells, padding=1)
- * u,out: (B,C,H,W) of io_dtype. */
+ *   u <- u + relax*(v + a_c*dt*Lap0(v) - u)      (Lap0: zero ghost cells, padding=1)
+ * u,out: (B,C,H,W) of io_dtype.  states: NULL, or room for (num_steps-1) tensors of u's shape and type that
+ * receive the inputs of steps 2..num_steps (what pde_explicit5_backward needs); required for num_steps > 1
+ * unless the plane is 64x64, 32x32 or 16x16 (those stay in registers over all steps, one launch). */
 int pde_explicit5_forward(int32_t B, int32_t C, int32_t H, int32_t W, int32_t io_dtype,
                           const void* u, const float* alpha_base, const float* channel_scaling,
                           float dt, float eps, float max_coeff, float relax,
-                          void* out, void* stream);
-size_t pde_explicit5_backward_workspace_bytes(int32_t B, int32_t C, int32_t H, int32_t W);
-/* gu, g_alpha_base (C), g_channel_scaling (C): overwritten. */
+                          int32_t num_steps, void* states, void* out, void* stream);
+size_t pde_explicit5_backward_workspace_bytes(int32_t B, int32_t C, int32_t H, int32_t W, int32_t io_dtype,
+                                              int32_t num_steps);
+/* gu, g_alpha_base (C), g_channel_scaling (C): overwritten.  states: as written by the forward call
+ * (may be NULL when num_steps == 1). */
 int pde_explicit5_backward(int32_t B, int32_t C, int32_t H, int32_t W, int32_t io_dtype,
-                           const void* u, const void* gout,
+                           const void* u, const void* states, const void* gout,
                            const float* alpha_base, const float* channel_scaling,
-                           float dt, float eps, float max_coeff, float relax,
+                           float dt, float eps, float max_coeff, float relax, int32_t num_steps,
                            void* gu, float* g_alpha_base, float* g_channel_scaling,
                            void* workspace, size_t workspace_bytes, void* stream);
 

@@ -55,5 +55,5 @@ def test_argument_validation_without_gpu():
     assert lib.pde_adi_forward_workspace_bytes(C.byref(d)) > 0
     assert lib.pde_adi_forward(C.byref(d), None, None, None, None, None, None, None, None, None, None, 0, None) == -1   # null pointers
     assert lib.pde_channel_mix_forward(0, 3, 16, 0, None, None, None, None) == -1
-    assert lib.pde_explicit5_forward(1, 1, 8, 6, 0, None, None, None, 0.01, 1e-6, 0.15, 0.1, None, None) == -1
+    assert lib.pde_explicit5_forward(1, 1, 8, 6, 0, None, None, None, 0.01, 1e-6, 0.15, 0.1, 1, None, None, None) == -1
     assert lib.pde_version().startswith(b"pdecnn-hip")

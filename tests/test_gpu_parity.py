@@ -327,6 +327,28 @@ def test_explicit_layers_vs_oracle():
     _compare(pl, lambda a, p: O.emotion_forward(a, p, Nx=40, Ny=40, T=0.004), u, gy, tol=2e-4)
 
 
+@pytest.mark.parametrize("size,steps,dtype", [(64, 1, torch.float32), (64, 3, torch.float32), (32, 4, torch.float32),
+                                              (16, 2, torch.float32), (24, 3, torch.float32), (40, 1, torch.float32),
+                                              (64, 2, torch.bfloat16), (24, 2, torch.bfloat16)])
+def test_explicit5_plane_sizes_and_steps_vs_oracle(size, steps, dtype):
+    """tiny_imagenet layer: the wave-per-plane kernels (64, 32, 16: plane in registers, all steps in one launch) and
+    the generic kernel (other sizes, one launch per step), ragged plane counts (B*C not a multiple of the 4 planes
+    of a workgroup), clamped and unclamped alpha."""
+    import cnn_with_pde_amd as P
+    g = torch.Generator().manual_seed(500 + size + steps)
+    C, B = 3, 7
+    layer = P.ImprovedDiffusionLayer(size, C, dt=0.5, num_steps=steps)
+    with torch.no_grad():
+        layer.alpha_base.copy_(torch.tensor([0.05, 0.3, 0.12]))
+        layer.channel_scaling.copy_(1 + 0.2 * torch.randn(C, generator=g))
+    u = torch.randn(B, C, size, size, generator=g)
+    gy = torch.randn(B, C, size, size, generator=g)
+    if dtype == torch.bfloat16:
+        u, gy = u.bfloat16().float(), gy.bfloat16().float()
+    _compare(layer, lambda a, p: O.tiny_forward(a, p, dt=0.5, num_steps=steps), u, gy,
+             tol=TOL if dtype == torch.float32 else 2e-2, dtype=dtype)
+
+
 @pytest.mark.parametrize("amp_dtype", [torch.float16, torch.bfloat16])
 def test_inside_autocast(amp_dtype):
     """cifar10.py:458-467 trains under autocast: a conv in front hands the layer a half tensor.  fp16 is
