@@ -60,6 +60,12 @@ SIGNATURES = {
     "pde_adi_mixed_backward_workspace_bytes": (_sz, [_D, _i32, _i32]),
     "pde_adi_mixed_backward": (C.c_int, [_D, _i32, _i32, _vp, _vp, _vp, _fp, C.POINTER(C.c_uint64), _vp, _fp, _fp, _fp, _fp,
                                          _fp, _fp, _fp, _fp, _fp, _vp, _vp, _sz, _vp]),
+    "pde_adi_small_supported": (C.c_int, [_D, _i32]),
+    "pde_adi_small_forward": (C.c_int, [_D, _i32, _i32, _vp, _vp, _vp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _vp, _sz,
+                                        _vp]),
+    "pde_adi_small_backward_workspace_bytes": (_sz, [_D, _i32, _i32]),
+    "pde_adi_small_backward": (C.c_int, [_D, _i32, _i32, _vp, _vp, _vp, _fp, _fp, C.POINTER(C.c_uint64), _vp,
+                                         _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _vp, _sz, _vp]),
     "pde_channel_mix_forward": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _fp, _vp, _vp]),
     "pde_channel_mix_backward_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "pde_channel_mix_backward": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _fp, _vp, _fp, _vp, _sz, _vp]),

@@ -39,6 +39,7 @@
 //     FOUR planes per lane so that each coefficient read serves four planes, and the planes of a lane are
 //     written as one value (Pack<J>) so that the packed form stays one flag away (make PACK=1: 4 % slower).
 #include "pde_adi_dev.h"
+#include "pde_adi_small.h"
 #include "pde_adi_launch.h"
 
 #include <cmath>
@@ -320,21 +321,60 @@ struct PgradArgs {
     float wx, wy;           // delta/h2 of the x / y sweeps
     float t_first[2];
     int have_axis[2];
+    // whole-layer kernels for C <= 4 (pde_adi_small.h): block C adds up the matrix and skip-weight partials
+    const float* gm_part;   // [gm_blocks][C][kGmStride] or null
+    float* gM;              // [C][C]
+    float* g_skip;          // scalar or null
+    const float* skip_w;
+    int gm_blocks;
 };
+constexpr int kGmStride = kSmallMaxC + 1;        // row c of the matrix gradient, then the skip-weight term
 
 __global__ __launch_bounds__(1024) void adi_pgrad_kernel(PgradArgs a) {
     __shared__ float sm[4][PDE_MAX_N][PDE_MAX_N + 1];
     const int N = a.N, c = blockIdx.x;
     const int tid = threadIdx.x;
+    if (c == a.C) {                                   // (only launched when gm_part is given)
+        if (tid < a.C * a.C) {
+            const int i = tid / a.C, j = tid % a.C;
+            float sum = 0.f;
+            for (int g = 0; g < a.gm_blocks; ++g) sum += a.gm_part[((size_t)g * a.C + i) * kGmStride + j];
+            a.gM[tid] = sum;
+        } else if (tid == a.C * a.C && a.g_skip != nullptr) {
+            float sum = 0.f;
+            for (int g = 0; g < a.gm_blocks; ++g)
+                for (int i = 0; i < a.C; ++i) sum += a.gm_part[((size_t)g * a.C + i) * kGmStride + kGmStride - 1];
+            const float sg = 1.0f / (1.0f + expf(-*a.skip_w));
+            *a.g_skip = (1.0f - sg) * sum;             // the kernel's partials already carry one factor sigmoid
+        }
+        return;
+    }
     const int h = tid / N, w = tid % N;
     const bool act = tid < N * N;
     if (act) {
+        // fixed summation order (deterministic), four groups at a time so that 16 loads are in flight per thread:
+        // the whole-layer kernels for C <= 4 leave one group per workgroup (up to 1024), and a serial chain of
+        // G dependent loads took 140 us at G = 128
         const int e = h * kLineStride + half_pos(w, N);
-        for (int arr = 0; arr < 4; ++arr) {
-            float sum = 0.f;
-            for (int g = 0; g < a.G; ++g) sum += a.part[(((size_t)g * a.C + c) * 4 + arr) * kImage + e];
-            sm[arr][h][w] = sum;
+        const size_t gs = (size_t)a.C * 4 * kImage;
+        const float* p0 = a.part + (size_t)c * 4 * kImage + e;
+        float s[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int arr = 0; arr < 4; ++arr) s[q][arr] = 0.f;
+        int g = 0;
+        for (; g + 4 <= a.G; g += 4) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int arr = 0; arr < 4; ++arr) s[q][arr] += p0[(size_t)(g + q) * gs + (size_t)arr * kImage];
         }
+        for (; g < a.G; ++g)
+#pragma unroll
+            for (int arr = 0; arr < 4; ++arr) s[0][arr] += p0[(size_t)g * gs + (size_t)arr * kImage];
+#pragma unroll
+        for (int arr = 0; arr < 4; ++arr) sm[arr][h][w] = (s[0][arr] + s[1][arr]) + (s[2][arr] + s[3][arr]);
     }
     __syncthreads();
     if (!act) return;
@@ -611,8 +651,10 @@ int launch_bwd_sweeps(const PdeAdiDesc* d, const void* gy, const void* y, const 
 int launch_pgrad(const PdeAdiDesc* d, const AxisWeights& w, const float* alpha_base, const float* beta_base,
                  const float* alpha_slope, const float* beta_slope, float* g_alpha_base, float* g_beta_base,
                  float* g_alpha_slope, float* g_beta_slope, const int* varying, const float* part, int G,
-                 hipStream_t st) {
+                 hipStream_t st, const float* gm_part = nullptr, float* gM = nullptr, float* g_skip = nullptr,
+                 const float* skip_w = nullptr) {
     PgradArgs pa{};
+    pa.gm_part = gm_part; pa.gM = gM; pa.g_skip = g_skip; pa.skip_w = skip_w; pa.gm_blocks = G;
     pa.part = part; pa.ab = alpha_base; pa.bb = beta_base; pa.as = alpha_slope; pa.bs = beta_slope;
     pa.g_ab = g_alpha_base; pa.g_bb = g_beta_base; pa.g_as = g_alpha_slope; pa.g_bs = g_beta_slope;
     pa.varying = varying;
@@ -623,7 +665,7 @@ int launch_pgrad(const PdeAdiDesc* d, const AxisWeights& w, const float* alpha_b
     pa.wx = w.wgt[0] / (1.0f + d->eps); pa.wy = w.wgt[1] / (1.0f + d->eps);
     pa.t_first[0] = w.tfirst[0]; pa.t_first[1] = w.tfirst[1];
     pa.have_axis[0] = w.have[0]; pa.have_axis[1] = w.have[1];
-    hipLaunchKernelGGL(adi_pgrad_kernel, dim3(d->C), dim3(1024), 0, st, pa);
+    hipLaunchKernelGGL(adi_pgrad_kernel, dim3(d->C + (gm_part ? 1 : 0)), dim3(1024), 0, st, pa);
     return check_launch();
 }
 
@@ -904,6 +946,130 @@ int pde_adi_mixed_backward(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t
     }
     return pde_adi_param_grads(d, sweeps_per_step, alpha_base, beta_base, alpha_slope, beta_slope, g_alpha_base,
                                g_beta_base, g_alpha_slope, g_beta_slope, steps_workspace, aws, stream);
+}
+
+// ---- the whole layer in ONE launch per pass: C <= 4 channels with a channel operator between the steps ----------
+// (pde_adi_small.h; the reference's own models: cifar10.py:253-258 C = 3 mixing before every step,
+// SVHN.py:238 C = 3 coupling after every step + skip blend)
+static int small_split(const PdeAdiDesc* d, int sps) {
+    PdeAdiDesc ds;
+    if (step_desc(d, sps, 0, ds) != PDE_OK) return kSplitAny;
+    const int sp = split_of(&ds);
+    for (int k = 1; k < d->num_sweeps / sps; ++k) {          // every step the same pattern
+        if (step_desc(d, sps, k, ds) != PDE_OK || split_of(&ds) != sp) return kSplitAny;
+    }
+    return sp;
+}
+static int small_grid(const PdeAdiDesc* d) { return d->B < 1024 ? d->B : 1024; }
+static int dispatch_small(bool fwd, const PdeAdiDesc* d, int split, const SmallArgs& sa, size_t lds, hipStream_t st) {
+    const int grid = small_grid(d);
+    switch (d->N) {
+#define PDE_SMALL_CASE(NN) case NN: return fwd ? adi_launch_small_fwd_##NN(d->io_dtype, split, &sa, grid, lds, st) \
+                                               : adi_launch_small_bwd_##NN(d->io_dtype, split, &sa, grid, lds, st);
+        PDE_SMALL_N_LIST
+#undef PDE_SMALL_CASE
+    }
+    return PDE_E_UNSUPPORTED_N;
+}
+static size_t small_lds_fwd(int C) { return (size_t)C * (2 * kRecFwdPad + kImage) * sizeof(float); }
+static size_t small_lds_bwd(int C) { return (size_t)C * (2 * kSmallRecB + 2 * kImage) * sizeof(float); }
+
+int pde_adi_small_supported(const PdeAdiDesc* d, int32_t sweeps_per_step) {
+    if (check_desc(d) != PDE_OK || d->C > kSmallMaxC) return 0;
+    if (sweeps_per_step != 2 && sweeps_per_step != 3) return 0;
+    if (d->num_sweeps % sweeps_per_step) return 0;
+    bool n_ok = false;
+#define PDE_SMALL_CASE(NN) n_ok |= (d->N == NN);
+    PDE_SMALL_N_LIST
+#undef PDE_SMALL_CASE
+    if (!n_ok) return 0;
+    const int sp = small_split(d, sweeps_per_step);
+    if (!((sp == kSplitStrang && sweeps_per_step == 3) || (sp == kSplitLie && sweeps_per_step == 2))) return 0;
+    AxisWeights w;
+    return axis_weights(d, w) == PDE_OK ? 1 : 0;
+}
+
+static void small_fill(SmallArgs& sa, const PdeAdiDesc* d, int sps, int mode, const void* steps_workspace, const float* M,
+                       const float* skip_weight) {
+    const char* ws = static_cast<const char*>(steps_workspace);
+    sa.coef = reinterpret_cast<const float*>(ws);
+    sa.varying = reinterpret_cast<const int*>(ws + coef_bytes(d));
+    sa.tabs = reinterpret_cast<const SweepTab*>(ws + steps_tab_offset(d));
+    sa.M = M; sa.skip_w = skip_weight;
+    sa.B = d->B; sa.C = d->C; sa.K = d->num_sweeps / sps; sa.mode = mode; sa.smooth3 = d->smooth3;
+    sa.step_scale = (float)pow(1.0 + (double)d->eps, -(double)sps);
+}
+
+int pde_adi_small_forward(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t mode, const void* u, void* y, void* states,
+                          const float* M, const float* skip_weight, const float* alpha_base, const float* beta_base,
+                          const float* alpha_slope, const float* beta_slope, float* kappa_max, float* kappa_max_host,
+                          void* kappa_event, void* steps_workspace, size_t workspace_bytes, void* stream) {
+    if (!pde_adi_small_supported(d, sweeps_per_step)) return PDE_E_BADARG;
+    if (!u || !y || !M || (mode != 1 && mode != 2) || (skip_weight && mode != 2)) return PDE_E_BADARG;
+    int rc = pde_adi_factor_steps(d, sweeps_per_step, alpha_base, beta_base, alpha_slope, beta_slope, kappa_max,
+                                  steps_workspace, workspace_bytes, stream);
+    if (rc != PDE_OK) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    rc = publish_kmax(kappa_max, kappa_max_host, kappa_event, d->num_sweeps, st);
+    if (rc != PDE_OK) return rc;
+    SmallArgs sa{};
+    small_fill(sa, d, sweeps_per_step, mode, steps_workspace, M, skip_weight);
+    sa.u = u; sa.out = y; sa.states = states;
+    return dispatch_small(true, d, small_split(d, sweeps_per_step), sa, small_lds_fwd(d->C), st);
+}
+
+size_t pde_adi_small_backward_workspace_bytes(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t num_checkpoints) {
+    if (!pde_adi_small_supported(d, sweeps_per_step) || num_checkpoints < 0) return 0;
+    const int G = small_grid(d), K = d->num_sweeps / sweeps_per_step;
+    return align_up((size_t)G * d->C * 4 * kImage * sizeof(float), 256) +
+           align_up((size_t)G * d->C * kGmStride * sizeof(float), 256) +
+           align_up((size_t)K * num_checkpoints * d->B * d->C * d->N * d->N * sizeof(float), 256);
+}
+
+int pde_adi_small_backward(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t mode, const void* gy, const void* u,
+                           const void* states, const float* M, const float* skip_weight, const uint64_t ckpt_mask[2],
+                           void* gu, const float* alpha_base, const float* beta_base, const float* alpha_slope,
+                           const float* beta_slope, float* g_alpha_base, float* g_beta_base, float* g_alpha_slope,
+                           float* g_beta_slope, float* gM, float* g_skip_weight, const void* steps_workspace,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+    if (!pde_adi_small_supported(d, sweeps_per_step)) return PDE_E_BADARG;
+    if (!gy || !u || !states || !M || !gu || !gM || !steps_workspace || !workspace || (mode != 1 && mode != 2) ||
+        (skip_weight && (mode != 2 || !g_skip_weight)) || !alpha_base || !beta_base || !alpha_slope || !beta_slope ||
+        !g_alpha_base || !g_beta_base || !g_alpha_slope || !g_beta_slope)
+        return PDE_E_BADARG;
+    PdeAdiDesc ds;
+    int rc = step_desc(d, sweeps_per_step, 0, ds);
+    if (rc != PDE_OK) return rc;
+    int nck, Sf;
+    rc = ckpt_plan(&ds, ckpt_mask, u, nck, Sf);            // the mask is relative to a step
+    if (rc != PDE_OK) return rc;
+    if (workspace_bytes < pde_adi_small_backward_workspace_bytes(d, sweeps_per_step, nck) || ((uintptr_t)workspace & 15))
+        return PDE_E_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int G = small_grid(d);
+    char* ws = static_cast<char*>(workspace);
+    float* part = reinterpret_cast<float*>(ws);            ws += align_up((size_t)G * d->C * 4 * kImage * sizeof(float), 256);
+    float* gm_part = reinterpret_cast<float*>(ws);         ws += align_up((size_t)G * d->C * kGmStride * sizeof(float), 256);
+    float* ckpt = nck ? reinterpret_cast<float*>(ws) : nullptr;
+    const int split = small_split(d, sweeps_per_step);
+    SmallArgs sa{};
+    small_fill(sa, d, sweeps_per_step, mode, steps_workspace, M, skip_weight);
+    sa.u = u; sa.ckpt = ckpt; sa.nck = nck;
+    sa.ck[0] = nck ? ckpt_mask[0] : 0ull; sa.ck[1] = nck ? ckpt_mask[1] : 0ull;
+    if (nck) {                                             // pre-pass: the forward again, parking the states inside the steps
+        SmallArgs fa = sa;
+        fa.out = nullptr; fa.states = nullptr;
+        rc = dispatch_small(true, d, split, fa, small_lds_fwd(d->C), st);
+        if (rc != PDE_OK) return rc;
+    }
+    sa.gy = gy; sa.out = gu; sa.states = const_cast<void*>(states); sa.part = part; sa.gm_part = gm_part;
+    rc = dispatch_small(false, d, split, sa, small_lds_bwd(d->C), st);
+    if (rc != PDE_OK) return rc;
+    AxisWeights w;
+    rc = axis_weights(d, w);
+    if (rc != PDE_OK) return rc;
+    return launch_pgrad(d, w, alpha_base, beta_base, alpha_slope, beta_slope, g_alpha_base, g_beta_base, g_alpha_slope,
+                        g_beta_slope, sa.varying, part, G, st, gm_part, gM, skip_weight ? g_skip_weight : nullptr, skip_weight);
 }
 
 int pde_adi_kappa_max(const PdeAdiDesc* d, const float* alpha_base, const float* beta_base, const float* alpha_slope,

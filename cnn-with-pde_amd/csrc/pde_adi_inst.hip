@@ -1,6 +1,10 @@
 // One translation unit per line length: compile with -DPDE_INST_N=<N>.
 #include "pde_adi_dev.h"
 #include "pde_adi_launch.h"
+#if PDE_INST_N == 16 || PDE_INST_N == 28 || PDE_INST_N == 32
+#define PDE_INST_SMALL 1
+#include "pde_adi_small.h"
+#endif
 
 #ifndef PDE_INST_N
 #error "compile with -DPDE_INST_N=<line length>"
@@ -59,5 +63,18 @@ int PDE_CAT(adi_launch_bwd_, PDE_INST_N)(int io, int split, const void* args, in
     const SweepArgs& sa = *static_cast<const SweepArgs*>(args);
     return io == PDE_IO_F32 ? bwd_io<float>(split, sa, grid, st) : bwd_io<bf16_t>(split, sa, grid, st);
 }
+
+#ifdef PDE_INST_SMALL
+int PDE_CAT(adi_launch_small_fwd_, PDE_INST_N)(int io, int split, const void* args, int grid, size_t lds, hipStream_t st) {
+    const SmallArgs& sa = *static_cast<const SmallArgs*>(args);
+    return io == PDE_IO_F32 ? small_fwd_io<PDE_INST_N, float>(split, sa, grid, lds, st)
+                            : small_fwd_io<PDE_INST_N, bf16_t>(split, sa, grid, lds, st);
+}
+int PDE_CAT(adi_launch_small_bwd_, PDE_INST_N)(int io, int split, const void* args, int grid, size_t lds, hipStream_t st) {
+    const SmallArgs& sa = *static_cast<const SmallArgs*>(args);
+    return io == PDE_IO_F32 ? small_bwd_io<PDE_INST_N, float>(split, sa, grid, lds, st)
+                            : small_bwd_io<PDE_INST_N, bf16_t>(split, sa, grid, lds, st);
+}
+#endif
 
 }  // namespace pde

@@ -16,4 +16,12 @@ constexpr int kJBwd = 2;         // planes per lane in the backward kernel
     int adi_launch_bwd_##NN(int io, int split, const void* args, int grid, hipStream_t st);
 PDE_DECLARE_N(8) PDE_DECLARE_N(12) PDE_DECLARE_N(16) PDE_DECLARE_N(20) PDE_DECLARE_N(24) PDE_DECLARE_N(28) PDE_DECLARE_N(32)
 #undef PDE_DECLARE_N
+
+// whole-layer kernels for C <= 4 (pde_adi_small.h), instantiated for the line lengths below
+#define PDE_SMALL_N_LIST PDE_SMALL_CASE(16) PDE_SMALL_CASE(28) PDE_SMALL_CASE(32)
+#define PDE_SMALL_CASE(NN)                                                                                \
+    int adi_launch_small_fwd_##NN(int io, int split, const void* args, int grid, size_t lds, hipStream_t st); \
+    int adi_launch_small_bwd_##NN(int io, int split, const void* args, int grid, size_t lds, hipStream_t st);
+PDE_SMALL_N_LIST
+#undef PDE_SMALL_CASE
 }  // namespace pde

@@ -14,7 +14,7 @@ import torch
 
 from . import _lib as L
 
-__all__ = ["Sweep", "adi_schedule", "adi_diffuse", "adi_diffuse_mixed", "plan_checkpoints", "kappa_max_async", "channel_mix", "skip_blend", "explicit5_step", "jacobi_diffuse",
+__all__ = ["Sweep", "adi_schedule", "adi_diffuse", "adi_diffuse_mixed", "adi_diffuse_small", "adi_small_supported", "plan_checkpoints", "kappa_max_async", "channel_mix", "skip_blend", "explicit5_step", "jacobi_diffuse",
            "timing_enable", "timing_read"]
 
 
@@ -303,6 +303,107 @@ class _AdiMixedFn(torch.autograd.Function):
                     "pde_adi_mixed_backward")
         gp = [g.reshape(s) for g, s in zip(gp, ctx.param_shapes)]
         return (g_a, *gp, gM.to(ctx.M_dtype), None, None, None, None, None, None, None)
+
+
+class _AdiSmallFn(torch.autograd.Function):
+    """A layer with a channel operator between its time steps at C <= 4, whole time loop in ONE launch per pass
+    (pde_adi_small_*): cifar10.py:84-112 ("pre"), SVHN.py:55-76 ("post", with the skip blend when ``skip_weight``
+    is given).  The sweep output of every step is kept for the backward, as autograd keeps it in the reference."""
+
+    @staticmethod
+    def forward(ctx, u, ab, bb, asl, bsl, M, skip_weight, steps, mode, smooth3, clamp_max, eps, ckpt, kmax_sink):
+        lib = L.load()
+        _require_cuda(u, ab, bb, asl, bsl, M, skip_weight)
+        B, Cc, N, _ = u.shape
+        if u.dtype not in (torch.float32, torch.bfloat16):
+            u = u.float()
+        u = u.contiguous()
+        sps, K = len(steps[0]), len(steps)
+        sweeps = tuple(s for st in steps for s in st)
+        p = [_as_chw(t, Cc, N) for t in (ab, bb, asl, bsl)]
+        Mf = M.detach().to(torch.float32).contiguous()
+        sw = None if skip_weight is None else skip_weight.detach().to(torch.float32).reshape(1).contiguous()
+        d = _make_desc(B, Cc, N, _io_dtype(u), sweeps, smooth3, clamp_max, eps)
+        sws = _workspace(lib.pde_adi_steps_workspace_bytes(C.byref(d), sps), u.device)
+        need_grad = any(ctx.needs_input_grad[:7])
+        want_kmax = need_grad and (ckpt == "auto" or kmax_sink is not None)
+        kdev = torch.empty(len(sweeps), dtype=torch.float32, device=u.device) if want_kmax else None
+        states = torch.empty((K,) + tuple(u.shape), dtype=u.dtype, device=u.device) if need_grad else None
+        y = torch.empty_like(u)
+        with torch.cuda.device(u.device):
+            host, ev = _kmax_channel(len(sweeps)) if want_kmax else (None, None)
+            L.check(lib.pde_adi_small_forward(C.byref(d), sps, 1 if mode == "pre" else 2, _ptr(u), _ptr(y), _ptr(states),
+                                              _ptr(Mf), _ptr(sw), *[_ptr(t) for t in p], _ptr(kdev), _ptr(host),
+                                              C.c_void_p(ev.cuda_event if ev is not None else 0),
+                                              _ptr(sws), sws.numel(), _stream()), "pde_adi_small_forward")
+            ctx.kmax_host, ctx.kmax_event = host, ev
+            if want_kmax and kmax_sink is not None:
+                kmax_sink.append((host, ev))
+        if need_grad:
+            ctx.save_for_backward(u, states, Mf, sw, *p)
+            ctx.sws = sws
+        ctx.cfg = (steps, mode, smooth3, clamp_max, eps, ckpt)
+        ctx.param_shapes = [t.shape for t in (ab, bb, asl, bsl)]
+        ctx.M_dtype = M.dtype
+        ctx.skip_meta = None if skip_weight is None else (skip_weight.dtype, skip_weight.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = L.load()
+        u, states, Mf, sw, *p = ctx.saved_tensors
+        steps, mode, smooth3, clamp_max, eps, ckpt = ctx.cfg
+        B, Cc, N, _ = u.shape
+        sps, K = len(steps[0]), len(steps)
+        sweeps = tuple(s for st in steps for s in st)
+        d = _make_desc(B, Cc, N, _io_dtype(u), sweeps, smooth3, clamp_max, eps)
+        if ckpt == "auto":
+            ctx.kmax_event.synchronize()
+            km = ctx.kmax_host.tolist()
+            bits = 0
+            for k in range(K):                           # one step-local mask for every step: the union
+                bits |= plan_checkpoints(km[k * sps:(k + 1) * sps])
+        else:
+            bits = int(ckpt)
+        mask = (C.c_uint64 * 2)(bits & (2 ** 64 - 1), bits >> 64)
+        ws = _workspace(lib.pde_adi_small_backward_workspace_bytes(C.byref(d), sps, bin(bits).count("1")), u.device)
+        g_in = gy.to(u.dtype).contiguous()
+        gu = torch.empty_like(g_in)
+        gp = [torch.empty_like(t) for t in p]
+        gM = torch.empty_like(Mf)
+        gsw = torch.empty(1, dtype=torch.float32, device=u.device) if sw is not None else None
+        with torch.cuda.device(u.device):
+            L.check(lib.pde_adi_small_backward(C.byref(d), sps, 1 if mode == "pre" else 2, _ptr(g_in), _ptr(u), _ptr(states),
+                                               _ptr(Mf), _ptr(sw), mask, _ptr(gu), *[_ptr(t) for t in p],
+                                               *[_ptr(t) for t in gp], _ptr(gM), _ptr(gsw), _ptr(ctx.sws), _ptr(ws),
+                                               ws.numel(), _stream()), "pde_adi_small_backward")
+        gp = [g.reshape(s) for g, s in zip(gp, ctx.param_shapes)]
+        gskip = None if sw is None else gsw.to(ctx.skip_meta[0]).reshape(ctx.skip_meta[1])
+        return (gu, *gp, gM.to(ctx.M_dtype), gskip, None, None, None, None, None, None, None)
+
+
+def adi_small_supported(u, steps, smooth3=False, clamp_max=None, eps=1e-6) -> bool:
+    """True when ``adi_diffuse_small`` can run this layer call (C <= 4, N in {16, 28, 32}, Strang or Lie steps)."""
+    if u.dim() != 4 or u.shape[2] != u.shape[3] or not u.is_cuda:
+        return False
+    B, Cc, N, _ = u.shape
+    if B == 0 or Cc > 4 or N > L.PDE_MAX_N or len(steps) * len(steps[0]) > L.PDE_MAX_SWEEPS:
+        return False
+    io = L.PDE_IO_BF16 if u.dtype == torch.bfloat16 else L.PDE_IO_F32
+    d = _make_desc(B, Cc, N, io, tuple(s for st in steps for s in st), smooth3, clamp_max, eps)
+    return bool(L.load().pde_adi_small_supported(C.byref(d), len(steps[0])))
+
+
+def adi_diffuse_small(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff, M, steps, mode: str, skip_weight=None,
+                      smooth3: bool = False, clamp_max: Optional[float] = None, eps: float = 1e-6, checkpoints="auto",
+                      kmax_sink: Optional[list] = None):
+    """``adi_diffuse_mixed`` (plus the SVHN skip blend when ``skip_weight`` is given) for C <= 4 channels: the whole
+    time loop in one launch forward and one backward.  Check ``adi_small_supported`` first."""
+    if mode not in ("pre", "post"):
+        raise ValueError(mode)
+    steps = tuple(tuple(st) for st in steps)
+    return _AdiSmallFn.apply(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff, M, skip_weight, steps, mode,
+                             bool(smooth3), clamp_max, float(eps), checkpoints, kmax_sink)
 
 
 def adi_diffuse_mixed(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff, M, steps, mode: str,

@@ -103,28 +103,44 @@ class _AdiBase(nn.Module):
         cache[key] = (sink[0][0], sink[0][1], old[2]) if sink else old
         return y
 
-    def _run(self, u, steps, M=None, mode=None):
+    def _run(self, u, steps, M=None, mode=None, skip_weight=None):
         """All steps of the layer.  One launch sequence holds at most PDE_MAX_SWEEPS sweeps: longer schedules
         (num_steps > 32 Strang steps) are cut into groups of whole steps, chained through autograd."""
         per = max(1, L.PDE_MAX_SWEEPS // len(steps[0]))
+        if len(steps) <= per:
+            return self._diffuse(u, [s for st in steps for s in st]) if M is None else \
+                self._diffuse_mixed(u, steps, M, mode, skip_weight)
+        u0 = u
         for i in range(0, len(steps), per):
             grp = steps[i:i + per]
-            if M is None:
-                u = self._diffuse(u, [s for st in grp for s in st])
-            else:
-                u = self._diffuse_mixed(u, grp, M, mode)
-        return u
+            u = self._diffuse(u, [s for st in grp for s in st]) if M is None else self._diffuse_mixed(u, grp, M, mode)
+        return u if skip_weight is None else F_.skip_blend(u0, u, skip_weight)
 
-    def _diffuse_mixed(self, u, steps, M, mode):
-        """All steps of a layer with a channel operator between them (functional.adi_diffuse_mixed); checkpoints
-        as in ``_diffuse`` (one step-local mask for every step)."""
+    #: False forces the per-step launch path (pde_adi_mixed_*) where the single-launch C <= 4 kernels would apply
+    small_channel_kernels = True
+
+    def _diffuse_mixed(self, u, steps, M, mode, skip_weight=None):
+        """All steps of a layer with a channel operator between them; checkpoints as in ``_diffuse`` (one step-local
+        mask for every step).  C <= 4 (the reference's own models): the whole time loop — and for SVHN the skip
+        blend — in one launch per pass (functional.adi_diffuse_small); otherwise one mixing and one sweep launch per
+        step (functional.adi_diffuse_mixed) and the skip blend as its own pass."""
         args = (self.alpha_base, self.beta_base, self.alpha_time_coeff, self.beta_time_coeff)
         kw = dict(smooth3=self._smooth3, clamp_max=self._clamp_max, eps=self.stability_eps)
+        small = self.small_channel_kernels and F_.adi_small_supported(u, steps, **kw)
+        u_in = u
+
+        def run(ck, sink=None):
+            if small:
+                return F_.adi_diffuse_small(u, *args, M, steps, mode, skip_weight, checkpoints=ck, kmax_sink=sink, **kw)
+            y = F_.adi_diffuse_mixed(u, *args, M, steps, mode, checkpoints=ck, kmax_sink=sink, **kw)
+            return y if skip_weight is None else F_.skip_blend(u_in, y, skip_weight)          # SVHN.py:73-74
+
         ck = self.checkpoint_policy
-        if not (torch.is_grad_enabled() and (u.requires_grad or M.requires_grad or any(p.requires_grad for p in args))):
+        live = (M, skip_weight) + args
+        if not (torch.is_grad_enabled() and (u.requires_grad or any(p is not None and p.requires_grad for p in live))):
             ck = 0
         if ck != "lagged":
-            return F_.adi_diffuse_mixed(u, *args, M, steps, mode, checkpoints=ck, **kw)
+            return run(ck)
         sps = len(steps[0])
 
         def plan(km):
@@ -135,7 +151,7 @@ class _AdiBase(nn.Module):
         old, cache, key = self._lagged_plan(("mixed", len(steps), sps, steps[0][0].t), u, args, kw,
                                             [s for st in steps for s in st], plan)
         sink = []
-        y = F_.adi_diffuse_mixed(u, *args, M, steps, mode, checkpoints=old[2], kmax_sink=sink, **kw)
+        y = run(old[2], sink)
         cache[key] = (sink[0][0], sink[0][1], old[2]) if sink else old
         return y
 
@@ -206,9 +222,8 @@ class SvhnDiffusionLayer(_AdiBase):
         self.skip_weight = nn.Parameter(torch.tensor(0.9))
 
     def forward(self, u):
-        original_u = u
-        u = self._run(u, self._schedule(), self.channel_coupling, "post")
-        return F_.skip_blend(original_u, u, self.skip_weight)          # SVHN.py:73-74
+        # SVHN.py:55-76: sweeps, coupling after every step, then sigmoid(w) u0 + (1 - sigmoid(w)) u
+        return self._run(u, self._schedule(), self.channel_coupling, "post", self.skip_weight)
 
 
 class EnhancedDiffusionLayer(_AdiBase):

@@ -168,6 +168,38 @@ int pde_adi_mixed_backward(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t
                            float* gM, const void* steps_workspace,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- K1, the whole layer in ONE launch per pass (C <= 4) -------------------------------------------
+ * The reference's own models run these layers at C = 3 (cifar10.py:253-258: mixing before every step;
+ * SVHN.py:238: coupling after every step, then the skip blend :73-74); per-step launches are bound by the
+ * host's launch rate there.  Here a workgroup owns all C channels of its samples (one wave per channel) and
+ * applies the C x C operator in registers at the step boundaries, so the forward is the factorisation kernel
+ * plus one launch, the backward one launch plus the gradient epilogue.
+ * pde_adi_small_supported: 1 when (d, sweeps_per_step) can take this path (C <= 4; N = 16, 28 or 32; every
+ * step x,y,x or x,y), else 0 — callers then use pde_adi_mixed_*.
+ * mode as in pde_adi_mixed_forward.  skip_weight: NULL, or (mode 2 only) the device scalar of SVHN.py:36: the
+ * output is sigmoid(w) u + (1 - sigmoid(w)) u_K.  states: NULL (inference), or K tensors of u's shape and
+ * type that receive the sweep output of every step (the backward needs them).  steps_workspace:
+ * pde_adi_steps_workspace_bytes(); kappa_*: as in pde_adi_forward. */
+int pde_adi_small_supported(const PdeAdiDesc* d, int32_t sweeps_per_step);
+int pde_adi_small_forward(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t mode,
+                          const void* u, void* y, void* states, const float* M, const float* skip_weight,
+                          const float* alpha_base, const float* beta_base,
+                          const float* alpha_slope, const float* beta_slope,
+                          float* kappa_max, float* kappa_max_host, void* kappa_event,
+                          void* steps_workspace, size_t workspace_bytes, void* stream);
+size_t pde_adi_small_backward_workspace_bytes(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t num_checkpoints);
+/* Exact reverse-mode derivative of pde_adi_small_forward: gu, the four coefficient gradients, gM (C,C) and,
+ * with a skip blend, *g_skip_weight; all overwritten.  ckpt_mask is relative to a step (bit i: keep the state
+ * after sweep i of every step instead of rebuilding it; the call then first re-runs the forward to park them). */
+int pde_adi_small_backward(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t mode,
+                           const void* gy, const void* u, const void* states, const float* M, const float* skip_weight,
+                           const uint64_t ckpt_mask[2], void* gu,
+                           const float* alpha_base, const float* beta_base,
+                           const float* alpha_slope, const float* beta_slope,
+                           float* g_alpha_base, float* g_beta_base, float* g_alpha_slope, float* g_beta_slope,
+                           float* gM, float* g_skip_weight, const void* steps_workspace,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- channel operators ------------------------------------------ */
 
 /* out[b,i,p] = sum_j M[i,j] u[b,j,p]  — cifar10.py:65-72 apply_channel_mixing and
