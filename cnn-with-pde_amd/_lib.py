@@ -34,6 +34,20 @@ class PdeAdiDesc(C.Structure):
                 ("clamp_max", C.c_float), ("eps", C.c_float), ("sweep", PdeSweep * PDE_MAX_SWEEPS)]
 
 
+class PdeSmallLayer(C.Structure):
+    """One of the layers that share an input in pde_adi_multi_* (include/pdecnn.h)."""
+    _fields_ = [("desc", C.POINTER(PdeAdiDesc)), ("sweeps_per_step", C.c_int32), ("mode", C.c_int32),
+                ("M", C.c_void_p), ("skip_weight", C.c_void_p),
+                ("alpha_base", C.c_void_p), ("beta_base", C.c_void_p), ("alpha_slope", C.c_void_p), ("beta_slope", C.c_void_p),
+                ("weight", C.c_float), ("weight_ptr", C.c_void_p), ("states", C.c_void_p),
+                ("steps_workspace", C.c_void_p), ("steps_workspace_bytes", C.c_size_t),
+                ("kappa_max", C.c_void_p), ("kappa_max_host", C.c_void_p),
+                ("gys", C.c_void_p), ("ckpt_mask", C.POINTER(C.c_uint64)),
+                ("g_alpha_base", C.c_void_p), ("g_beta_base", C.c_void_p), ("g_alpha_slope", C.c_void_p),
+                ("g_beta_slope", C.c_void_p), ("gM", C.c_void_p), ("g_skip_weight", C.c_void_p), ("g_weight", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
 class PdeError(RuntimeError):
     pass
 
@@ -66,6 +80,8 @@ SIGNATURES = {
     "pde_adi_small_backward_workspace_bytes": (_sz, [_D, _i32, _i32]),
     "pde_adi_small_backward": (C.c_int, [_D, _i32, _i32, _vp, _vp, _vp, _fp, _fp, C.POINTER(C.c_uint64), _vp,
                                          _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _vp, _sz, _vp]),
+    "pde_adi_multi_forward": (C.c_int, [_i32, C.POINTER(PdeSmallLayer), _vp, _vp, _vp, _vp]),
+    "pde_adi_multi_backward": (C.c_int, [_i32, C.POINTER(PdeSmallLayer), _vp, _vp, _vp, _vp]),
     "pde_channel_mix_forward": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _fp, _vp, _vp]),
     "pde_channel_mix_backward_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "pde_channel_mix_backward": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _fp, _vp, _fp, _vp, _sz, _vp]),

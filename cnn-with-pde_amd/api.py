@@ -1,11 +1,15 @@
 """Public surface of cnn_with_pde_amd."""
 from . import _lib
 from ._lib import PdeError, LIB_PATH
-from .functional import (Sweep, adi_schedule, adi_diffuse, plan_checkpoints, channel_mix, explicit5_step, jacobi_diffuse,
-                         timing_enable, timing_read)
+from .functional import (Sweep, adi_schedule, adi_diffuse, adi_diffuse_mixed, adi_diffuse_small, adi_diffuse_multi,
+                         plan_checkpoints, channel_mix, explicit5_step, jacobi_diffuse, timing_enable, timing_read)
 from .dist import shard_range, shard_batch, GradBucket
 from .layers import (MnistDiffusionLayer, FashionDiffusionLayer, SvhnDiffusionLayer, EnhancedDiffusionLayer,
                      LearnableDiffusionLayer, ImprovedDiffusionLayer, PDELayer)
+from . import models
+from .models import (MnistPDEClassifier, FashionPDEClassifier, SvhnPDEClassifier, SpatialAttention, MultiScaleExtractor,
+                     EnhancedFC, CIFAR10PDENoConv, DiffusionPair, TinyImageNetClassifier, EmotionDiffusionClassifier,
+                     diffuse_shared_input)
 
 #: (reference script, reference class name) -> class here
 REFERENCE_CLASSES = {
@@ -16,6 +20,15 @@ REFERENCE_CLASSES = {
     ("cifar_2version", "LearnableDiffusionLayer"): LearnableDiffusionLayer,
     ("tiny_imagenet", "ImprovedDiffusionLayer"): ImprovedDiffusionLayer,
     ("emotion_recognition", "PDELayer"): PDELayer,
+    ("mnist_test", "PDEClassifier"): MnistPDEClassifier,
+    ("fashion_mnist", "FashionPDEClassifier"): FashionPDEClassifier,
+    ("SVHN", "PDEClassifier"): SvhnPDEClassifier,
+    ("cifar10", "SpatialAttention"): SpatialAttention,
+    ("cifar10", "MultiScaleExtractor"): MultiScaleExtractor,
+    ("cifar10", "EnhancedFC"): EnhancedFC,
+    ("cifar10", "CIFAR10PDENoConv"): CIFAR10PDENoConv,
+    ("tiny_imagenet", "ImprovedTinyImageNetClassifier"): TinyImageNetClassifier,
+    ("emotion_recognition", "DiffusionClassifier"): EmotionDiffusionClassifier,
 }
 
 
@@ -23,7 +36,10 @@ def library_version() -> str:
     return _lib.load().pde_version().decode()
 
 
-__all__ = ["PdeError", "LIB_PATH", "Sweep", "adi_schedule", "adi_diffuse", "plan_checkpoints", "channel_mix", "explicit5_step",
+__all__ = ["PdeError", "LIB_PATH", "Sweep", "adi_schedule", "adi_diffuse", "adi_diffuse_mixed", "adi_diffuse_small",
+           "adi_diffuse_multi", "plan_checkpoints", "channel_mix", "explicit5_step",
            "jacobi_diffuse", "timing_enable", "timing_read", "MnistDiffusionLayer", "FashionDiffusionLayer",
            "SvhnDiffusionLayer", "EnhancedDiffusionLayer", "LearnableDiffusionLayer", "ImprovedDiffusionLayer",
-           "PDELayer", "REFERENCE_CLASSES", "library_version", "shard_range", "shard_batch", "GradBucket"]
+           "PDELayer", "models", "MnistPDEClassifier", "FashionPDEClassifier", "SvhnPDEClassifier", "SpatialAttention",
+           "MultiScaleExtractor", "EnhancedFC", "CIFAR10PDENoConv", "DiffusionPair", "TinyImageNetClassifier",
+           "EmotionDiffusionClassifier", "diffuse_shared_input", "REFERENCE_CLASSES", "library_version", "shard_range", "shard_batch", "GradBucket"]

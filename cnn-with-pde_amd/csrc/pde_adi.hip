@@ -325,10 +325,10 @@ struct PgradArgs {
     const float* gm_part;   // [gm_blocks][C][kGmStride] or null
     float* gM;              // [C][C]
     float* g_skip;          // scalar or null
+    float* g_w;             // scalar or null: d/d(weight of this layer's output in the launch's weighted sum)
     const float* skip_w;
     int gm_blocks;
 };
-constexpr int kGmStride = kSmallMaxC + 1;        // row c of the matrix gradient, then the skip-weight term
 
 __global__ __launch_bounds__(1024) void adi_pgrad_kernel(PgradArgs a) {
     __shared__ float sm[4][PDE_MAX_N][PDE_MAX_N + 1];
@@ -343,9 +343,14 @@ __global__ __launch_bounds__(1024) void adi_pgrad_kernel(PgradArgs a) {
         } else if (tid == a.C * a.C && a.g_skip != nullptr) {
             float sum = 0.f;
             for (int g = 0; g < a.gm_blocks; ++g)
-                for (int i = 0; i < a.C; ++i) sum += a.gm_part[((size_t)g * a.C + i) * kGmStride + kGmStride - 1];
+                for (int i = 0; i < a.C; ++i) sum += a.gm_part[((size_t)g * a.C + i) * kGmStride + kSmallMaxC];
             const float sg = 1.0f / (1.0f + expf(-*a.skip_w));
             *a.g_skip = (1.0f - sg) * sum;             // the kernel's partials already carry one factor sigmoid
+        } else if (tid == a.C * a.C + 1 && a.g_w != nullptr) {
+            float sum = 0.f;
+            for (int g = 0; g < a.gm_blocks; ++g)
+                for (int i = 0; i < a.C; ++i) sum += a.gm_part[((size_t)g * a.C + i) * kGmStride + kGmStride - 1];
+            *a.g_w = sum;
         }
         return;
     }
@@ -652,9 +657,9 @@ int launch_pgrad(const PdeAdiDesc* d, const AxisWeights& w, const float* alpha_b
                  const float* alpha_slope, const float* beta_slope, float* g_alpha_base, float* g_beta_base,
                  float* g_alpha_slope, float* g_beta_slope, const int* varying, const float* part, int G,
                  hipStream_t st, const float* gm_part = nullptr, float* gM = nullptr, float* g_skip = nullptr,
-                 const float* skip_w = nullptr) {
+                 const float* skip_w = nullptr, float* g_w = nullptr) {
     PgradArgs pa{};
-    pa.gm_part = gm_part; pa.gM = gM; pa.g_skip = g_skip; pa.skip_w = skip_w; pa.gm_blocks = G;
+    pa.gm_part = gm_part; pa.gM = gM; pa.g_skip = g_skip; pa.skip_w = skip_w; pa.g_w = g_w; pa.gm_blocks = G;
     pa.part = part; pa.ab = alpha_base; pa.bb = beta_base; pa.as = alpha_slope; pa.bs = beta_slope;
     pa.g_ab = g_alpha_base; pa.g_bb = g_beta_base; pa.g_as = g_alpha_slope; pa.g_bs = g_beta_slope;
     pa.varying = varying;
@@ -989,33 +994,56 @@ int pde_adi_small_supported(const PdeAdiDesc* d, int32_t sweeps_per_step) {
     return axis_weights(d, w) == PDE_OK ? 1 : 0;
 }
 
-static void small_fill(SmallArgs& sa, const PdeAdiDesc* d, int sps, int mode, const void* steps_workspace, const float* M,
-                       const float* skip_weight) {
+static void small_fill(SmallLayer& sl, const PdeAdiDesc* d, int sps, int mode, const void* steps_workspace, const float* M,
+                       const float* skip_weight, float weight, const float* weight_ptr = nullptr) {
     const char* ws = static_cast<const char*>(steps_workspace);
-    sa.coef = reinterpret_cast<const float*>(ws);
-    sa.varying = reinterpret_cast<const int*>(ws + coef_bytes(d));
-    sa.tabs = reinterpret_cast<const SweepTab*>(ws + steps_tab_offset(d));
-    sa.M = M; sa.skip_w = skip_weight;
-    sa.B = d->B; sa.C = d->C; sa.K = d->num_sweeps / sps; sa.mode = mode; sa.smooth3 = d->smooth3;
-    sa.step_scale = (float)pow(1.0 + (double)d->eps, -(double)sps);
+    sl.coef = reinterpret_cast<const float*>(ws);
+    sl.varying = reinterpret_cast<const int*>(ws + coef_bytes(d));
+    sl.tabs = reinterpret_cast<const SweepTab*>(ws + steps_tab_offset(d));
+    sl.M = M; sl.skip_w = skip_weight;
+    sl.K = d->num_sweeps / sps; sl.mode = mode; sl.smooth3 = d->smooth3;
+    sl.step_scale = (float)pow(1.0 + (double)d->eps, -(double)sps);
+    sl.w = weight; sl.wp = weight_ptr;
 }
 
-int pde_adi_small_forward(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t mode, const void* u, void* y, void* states,
-                          const float* M, const float* skip_weight, const float* alpha_base, const float* beta_base,
-                          const float* alpha_slope, const float* beta_slope, float* kappa_max, float* kappa_max_host,
-                          void* kappa_event, void* steps_workspace, size_t workspace_bytes, void* stream) {
-    if (!pde_adi_small_supported(d, sweeps_per_step)) return PDE_E_BADARG;
-    if (!u || !y || !M || (mode != 1 && mode != 2) || (skip_weight && mode != 2)) return PDE_E_BADARG;
-    int rc = pde_adi_factor_steps(d, sweeps_per_step, alpha_base, beta_base, alpha_slope, beta_slope, kappa_max,
-                                  steps_workspace, workspace_bytes, stream);
+// layers of one launch must agree on everything the kernel instantiation and the grid depend on
+static int multi_check(int32_t L, const PdeSmallLayer* layers) {
+    if (L < 1 || L > kSmallMaxL || !layers) return PDE_E_BADARG;
+    const PdeAdiDesc* d0 = layers[0].desc;
+    for (int i = 0; i < L; ++i) {
+        const PdeSmallLayer& y = layers[i];
+        if (!y.desc || !pde_adi_small_supported(y.desc, y.sweeps_per_step)) return PDE_E_BADARG;
+        if (!y.M || (y.mode != 1 && y.mode != 2) || (y.skip_weight && y.mode != 2)) return PDE_E_BADARG;
+        if (y.desc->B != d0->B || y.desc->C != d0->C || y.desc->N != d0->N || y.desc->io_dtype != d0->io_dtype ||
+            y.sweeps_per_step != layers[0].sweeps_per_step)
+            return PDE_E_BADARG;
+        if (L > 1 && y.mode != 1) return PDE_E_BADARG;     // shared-input groups exist for the mixing-first layers only
+        if (!y.alpha_base || !y.beta_base || !y.alpha_slope || !y.beta_slope || !y.steps_workspace) return PDE_E_BADARG;
+    }
+    return PDE_OK;
+}
+
+int pde_adi_multi_forward(int32_t num_layers, const PdeSmallLayer* layers, const void* u, void* out, void* kappa_event,
+                          void* stream) {
+    int rc = multi_check(num_layers, layers);
     if (rc != PDE_OK) return rc;
+    if (!u || !out) return PDE_E_BADARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    rc = publish_kmax(kappa_max, kappa_max_host, kappa_event, d->num_sweeps, st);
-    if (rc != PDE_OK) return rc;
+    const PdeAdiDesc* d0 = layers[0].desc;
     SmallArgs sa{};
-    small_fill(sa, d, sweeps_per_step, mode, steps_workspace, M, skip_weight);
-    sa.u = u; sa.out = y; sa.states = states;
-    return dispatch_small(true, d, small_split(d, sweeps_per_step), sa, small_lds_fwd(d->C), st);
+    sa.u = u; sa.out = out; sa.B = d0->B; sa.C = d0->C; sa.L = num_layers;
+    for (int i = 0; i < num_layers; ++i) {
+        const PdeSmallLayer& y = layers[i];
+        rc = pde_adi_factor_steps(y.desc, y.sweeps_per_step, y.alpha_base, y.beta_base, y.alpha_slope, y.beta_slope,
+                                  y.kappa_max, y.steps_workspace, y.steps_workspace_bytes, stream);
+        if (rc != PDE_OK) return rc;
+        rc = publish_kmax(y.kappa_max, y.kappa_max_host, nullptr, y.desc->num_sweeps, st);
+        if (rc != PDE_OK) return rc;
+        small_fill(sa.layer[i], y.desc, y.sweeps_per_step, y.mode, y.steps_workspace, y.M, y.skip_weight, y.weight, y.weight_ptr);
+        sa.layer[i].states = y.states;
+    }
+    if (kappa_event && hipEventRecord(static_cast<hipEvent_t>(kappa_event), st) != hipSuccess) return PDE_E_LAUNCH;
+    return dispatch_small(true, d0, small_split(d0, layers[0].sweeps_per_step), sa, small_lds_fwd(d0->C), st);
 }
 
 size_t pde_adi_small_backward_workspace_bytes(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t num_checkpoints) {
@@ -1026,50 +1054,93 @@ size_t pde_adi_small_backward_workspace_bytes(const PdeAdiDesc* d, int32_t sweep
            align_up((size_t)K * num_checkpoints * d->B * d->C * d->N * d->N * sizeof(float), 256);
 }
 
+int pde_adi_multi_backward(int32_t num_layers, const PdeSmallLayer* layers, const void* gy, const void* u, void* gu,
+                           void* stream) {
+    int rc = multi_check(num_layers, layers);
+    if (rc != PDE_OK) return rc;
+    if (!u || !gu) return PDE_E_BADARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const PdeAdiDesc* d0 = layers[0].desc;
+    const int sps = layers[0].sweeps_per_step, G = small_grid(d0), split = small_split(d0, sps);
+    SmallArgs sa{};
+    sa.u = u; sa.gy = gy; sa.out = gu; sa.B = d0->B; sa.C = d0->C; sa.L = num_layers;
+    bool any_ck = false;
+    for (int i = 0; i < num_layers; ++i) {
+        const PdeSmallLayer& y = layers[i];
+        if (!y.states || !y.gM || !y.workspace || (!gy && !y.gys) || !y.g_alpha_base || !y.g_beta_base || !y.g_alpha_slope ||
+            !y.g_beta_slope || (y.skip_weight && !y.g_skip_weight))
+            return PDE_E_BADARG;
+        PdeAdiDesc ds;
+        rc = step_desc(y.desc, sps, 0, ds);
+        if (rc != PDE_OK) return rc;
+        int nck, Sf;
+        rc = ckpt_plan(&ds, y.ckpt_mask, u, nck, Sf);      // the mask is relative to a step
+        if (rc != PDE_OK) return rc;
+        if (y.workspace_bytes < pde_adi_small_backward_workspace_bytes(y.desc, sps, nck) || ((uintptr_t)y.workspace & 15))
+            return PDE_E_WORKSPACE;
+        SmallLayer& sl = sa.layer[i];
+        small_fill(sl, y.desc, sps, y.mode, y.steps_workspace, y.M, y.skip_weight, y.weight, y.weight_ptr);
+        char* ws = static_cast<char*>(y.workspace);
+        sl.part = reinterpret_cast<float*>(ws);            ws += align_up((size_t)G * d0->C * 4 * kImage * sizeof(float), 256);
+        sl.gm_part = reinterpret_cast<float*>(ws);         ws += align_up((size_t)G * d0->C * kGmStride * sizeof(float), 256);
+        sl.ckpt = nck ? reinterpret_cast<float*>(ws) : nullptr;
+        sl.nck = nck;
+        sl.ck[0] = nck ? y.ckpt_mask[0] : 0ull; sl.ck[1] = nck ? y.ckpt_mask[1] : 0ull;
+        any_ck |= nck != 0;
+    }
+    if (any_ck) {                                          // pre-pass: the forward again, parking the states inside the steps
+        SmallArgs fa = sa;
+        fa.out = nullptr; fa.gy = nullptr;
+        rc = dispatch_small(true, d0, split, fa, small_lds_fwd(d0->C), st);
+        if (rc != PDE_OK) return rc;
+    }
+    for (int i = 0; i < num_layers; ++i) {
+        sa.layer[i].states = const_cast<void*>(layers[i].states);
+        sa.layer[i].gys = layers[i].gys;
+    }
+    rc = dispatch_small(false, d0, split, sa, small_lds_bwd(d0->C), st);
+    if (rc != PDE_OK) return rc;
+    for (int i = 0; i < num_layers; ++i) {
+        const PdeSmallLayer& y = layers[i];
+        AxisWeights w;
+        rc = axis_weights(y.desc, w);
+        if (rc != PDE_OK) return rc;
+        rc = launch_pgrad(y.desc, w, y.alpha_base, y.beta_base, y.alpha_slope, y.beta_slope, y.g_alpha_base, y.g_beta_base,
+                          y.g_alpha_slope, y.g_beta_slope, sa.layer[i].varying, sa.layer[i].part, G, st, sa.layer[i].gm_part,
+                          y.gM, y.skip_weight ? y.g_skip_weight : nullptr, y.skip_weight, y.g_weight);
+        if (rc != PDE_OK) return rc;
+    }
+    return PDE_OK;
+}
+
+// one layer: thin wrappers
+int pde_adi_small_forward(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t mode, const void* u, void* y, void* states,
+                          const float* M, const float* skip_weight, const float* alpha_base, const float* beta_base,
+                          const float* alpha_slope, const float* beta_slope, float* kappa_max, float* kappa_max_host,
+                          void* kappa_event, void* steps_workspace, size_t workspace_bytes, void* stream) {
+    PdeSmallLayer l{};
+    l.desc = d; l.sweeps_per_step = sweeps_per_step; l.mode = mode; l.M = M; l.skip_weight = skip_weight;
+    l.alpha_base = alpha_base; l.beta_base = beta_base; l.alpha_slope = alpha_slope; l.beta_slope = beta_slope;
+    l.weight = 1.0f; l.states = states; l.steps_workspace = steps_workspace; l.steps_workspace_bytes = workspace_bytes;
+    l.kappa_max = kappa_max; l.kappa_max_host = kappa_max_host;
+    return pde_adi_multi_forward(1, &l, u, y, kappa_event, stream);
+}
+
 int pde_adi_small_backward(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t mode, const void* gy, const void* u,
                            const void* states, const float* M, const float* skip_weight, const uint64_t ckpt_mask[2],
                            void* gu, const float* alpha_base, const float* beta_base, const float* alpha_slope,
                            const float* beta_slope, float* g_alpha_base, float* g_beta_base, float* g_alpha_slope,
                            float* g_beta_slope, float* gM, float* g_skip_weight, const void* steps_workspace,
                            void* workspace, size_t workspace_bytes, void* stream) {
-    if (!pde_adi_small_supported(d, sweeps_per_step)) return PDE_E_BADARG;
-    if (!gy || !u || !states || !M || !gu || !gM || !steps_workspace || !workspace || (mode != 1 && mode != 2) ||
-        (skip_weight && (mode != 2 || !g_skip_weight)) || !alpha_base || !beta_base || !alpha_slope || !beta_slope ||
-        !g_alpha_base || !g_beta_base || !g_alpha_slope || !g_beta_slope)
-        return PDE_E_BADARG;
-    PdeAdiDesc ds;
-    int rc = step_desc(d, sweeps_per_step, 0, ds);
-    if (rc != PDE_OK) return rc;
-    int nck, Sf;
-    rc = ckpt_plan(&ds, ckpt_mask, u, nck, Sf);            // the mask is relative to a step
-    if (rc != PDE_OK) return rc;
-    if (workspace_bytes < pde_adi_small_backward_workspace_bytes(d, sweeps_per_step, nck) || ((uintptr_t)workspace & 15))
-        return PDE_E_WORKSPACE;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const int G = small_grid(d);
-    char* ws = static_cast<char*>(workspace);
-    float* part = reinterpret_cast<float*>(ws);            ws += align_up((size_t)G * d->C * 4 * kImage * sizeof(float), 256);
-    float* gm_part = reinterpret_cast<float*>(ws);         ws += align_up((size_t)G * d->C * kGmStride * sizeof(float), 256);
-    float* ckpt = nck ? reinterpret_cast<float*>(ws) : nullptr;
-    const int split = small_split(d, sweeps_per_step);
-    SmallArgs sa{};
-    small_fill(sa, d, sweeps_per_step, mode, steps_workspace, M, skip_weight);
-    sa.u = u; sa.ckpt = ckpt; sa.nck = nck;
-    sa.ck[0] = nck ? ckpt_mask[0] : 0ull; sa.ck[1] = nck ? ckpt_mask[1] : 0ull;
-    if (nck) {                                             // pre-pass: the forward again, parking the states inside the steps
-        SmallArgs fa = sa;
-        fa.out = nullptr; fa.states = nullptr;
-        rc = dispatch_small(true, d, split, fa, small_lds_fwd(d->C), st);
-        if (rc != PDE_OK) return rc;
-    }
-    sa.gy = gy; sa.out = gu; sa.states = const_cast<void*>(states); sa.part = part; sa.gm_part = gm_part;
-    rc = dispatch_small(false, d, split, sa, small_lds_bwd(d->C), st);
-    if (rc != PDE_OK) return rc;
-    AxisWeights w;
-    rc = axis_weights(d, w);
-    if (rc != PDE_OK) return rc;
-    return launch_pgrad(d, w, alpha_base, beta_base, alpha_slope, beta_slope, g_alpha_base, g_beta_base, g_alpha_slope,
-                        g_beta_slope, sa.varying, part, G, st, gm_part, gM, skip_weight ? g_skip_weight : nullptr, skip_weight);
+    if (!gy) return PDE_E_BADARG;
+    PdeSmallLayer l{};
+    l.desc = d; l.sweeps_per_step = sweeps_per_step; l.mode = mode; l.M = M; l.skip_weight = skip_weight;
+    l.alpha_base = alpha_base; l.beta_base = beta_base; l.alpha_slope = alpha_slope; l.beta_slope = beta_slope;
+    l.weight = 1.0f; l.states = const_cast<void*>(states); l.steps_workspace = const_cast<void*>(steps_workspace);
+    l.ckpt_mask = ckpt_mask; l.g_alpha_base = g_alpha_base; l.g_beta_base = g_beta_base; l.g_alpha_slope = g_alpha_slope;
+    l.g_beta_slope = g_beta_slope; l.gM = gM; l.g_skip_weight = g_skip_weight; l.workspace = workspace;
+    l.workspace_bytes = workspace_bytes;
+    return pde_adi_multi_backward(1, &l, gy, u, gu, stream);
 }
 
 int pde_adi_kappa_max(const PdeAdiDesc* d, const float* alpha_base, const float* beta_base, const float* alpha_slope,

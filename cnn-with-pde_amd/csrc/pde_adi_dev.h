@@ -109,6 +109,16 @@ __device__ __forceinline__ void lds_dma16_s(const float* sbase, unsigned voff, f
     const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)lds_wave_base);
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(voff), "s"(sbase) : "memory");
 }
+// The same with the LDS destination given as a byte address (wave-uniform): for callers whose LDS pointers reach the
+// call through enough control flow that hipcc no longer proves their address space (the generic -> LDS cast then
+// fails in the backend: "V_CMP_NE_U32_e32 0, $src_shared_base").
+__device__ __forceinline__ unsigned lds_byte_address(const float* lds_base) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const float*)lds_base;
+}
+__device__ __forceinline__ void lds_dma16_a(const float* sbase, unsigned voff, unsigned lds_bytes) {
+    const unsigned lds = __builtin_amdgcn_readfirstlane(lds_bytes);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(voff), "s"(sbase) : "memory");
+}
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 #ifdef PDE_STAMP

@@ -22,27 +22,47 @@ namespace pde {
 namespace {
 
 constexpr int kSmallMaxC = 4;
+constexpr int kSmallMaxL = 4;                                     // layers that share an input in one launch
 constexpr int kSmallRecB = ((kRecBwd / 4 + 63) / 64) * 256;      // backward record slot (whole 1-KB DMA pieces)
+constexpr int kGmStride = kSmallMaxC + 2;                         // row c of the matrix gradient | skip term | <g, y_i>
 
-struct SmallArgs {
-    const void* u;          // layer input (B,C,N,N)
-    const void* gy;         // bwd: dL/dy
-    void* out;              // fwd: y (null: checkpoint pre-pass only); bwd: gu
-    void* states;           // [K][B][C][N][N] of the tensor type: sweep output of every step (fwd: null = do not keep)
-    float* ckpt;            // [K][nck][B][C][N][N] fp32: states inside a step (null: none)
+// One layer of the launch.  Several layers that read the SAME input (cifar10.py:272-274: three, cifar_2version.py:
+// 287-288: two) run one after the other inside the launch: out = sum_i w_i y_i (cifar10.py:277-280 without the
+// attention gates), and in the backward gu = sum_i gu_i.
+struct SmallLayer {
     const float* coef;      // [S][C][kRecStride]
     const SweepTab* tabs;   // [K] one table per step
     const int* varying;     // [C]
     const float* M;         // [C][C] channel_mixing / channel_coupling
     const float* skip_w;    // SVHN skip_weight (device scalar); null: no skip blend
+    void* states;           // [K][B][C][N][N] of the tensor type: sweep output of every step (fwd: null = do not keep)
+    float* ckpt;            // [K][nck][B][C][N][N] fp32: states inside a step (null: none)
+    const void* gys;        // bwd: dL/dy_i on top of w_i dL/dout (null: none)
     float* part;            // bwd: [grid][C][4][kImage]
-    float* gm_part;         // bwd: [grid][C][kSmallMaxC + 1]: row c of the matrix gradient, then the skip term
+    float* gm_part;         // bwd: [grid][C][kGmStride]
     unsigned long long ck[2];   // bit i: the state after sweep i of EVERY step is checkpointed
     int nck;
-    int B, C, K, mode;      // mode 1: operator before every step, 2: after
+    int K, mode;            // mode 1: operator before every step, 2: after
     int smooth3;
     float step_scale;       // (1+eps)^-(sweeps per step): undoes the factor the adjoint solves carry
+    float w;                // weight of this layer's output in `out` ...
+    const float* wp;        // ... or, when not null, a device scalar holding it
 };
+struct SmallArgs {
+    const void* u;          // the layers' common input (B,C,N,N)
+    const void* gy;         // bwd: dL/dout (null: only the gys of the layers)
+    void* out;              // fwd: sum_i w_i y_i (null: checkpoint pre-pass only); bwd: gu
+    int B, C, L, pad;
+    SmallLayer layer[kSmallMaxL];
+};
+// The layer descriptors are read where they lie, in the kernel-argument segment, with scalar loads at a run-time
+// index (an argument array indexed at run time would be held whole in SGPRs and spilled).
+typedef const __attribute__((address_space(4))) SmallLayer* ConstLayer;
+__device__ __forceinline__ ConstLayer small_layer(int i) {
+    const __attribute__((address_space(4))) char* base =
+        (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    return (ConstLayer)(base + __builtin_offsetof(SmallArgs, layer)) + i;
+}
 
 __device__ __forceinline__ float sigmoid_f(float w) { return 1.0f / (1.0f + expf(-w)); }
 
@@ -88,92 +108,120 @@ __global__ __launch_bounds__(64 * kSmallMaxC) void adi_small_fwd_kernel(SmallArg
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, c = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hf = lane >> 5, l = lane & 31;
-    const int nC = a.C, S = a.K * SPS;
+    const int nC = a.C;
     float* ring = smem + (size_t)c * 2 * kRecFwdPad;                      // wave-private [2][kRecFwdPad]
+    const unsigned ring_lds = lds_byte_address(smem) + (unsigned)c * 2u * kRecFwdPad * 4u;
     float* imgs = smem + (size_t)nC * 2 * kRecFwdPad;                     // [C][kImage]: plane I/O, re-layout, exchange
     float* T = imgs + (size_t)c * kImage;
     for (int e = lane; e < kImage; e += 64) T[e] = 0.f;                  // rows >= N stay zero: idle lanes read zeros
     const IO* u = static_cast<const IO*>(a.u);
     IO* y = static_cast<IO*>(a.out);
-    IO* st = static_cast<IO*>(a.states);
     const size_t tens = (size_t)a.B * nC * N * N;
-    float mrow[kSmallMaxC];                                               // my row of the operator
-#pragma unroll
-    for (int j = 0; j < kSmallMaxC; ++j) mrow[j] = (j < nC) ? a.M[c * nC + j] : 0.f;
-    const float sk = a.skip_w ? sigmoid_f(*a.skip_w) : 0.f;
 
-    auto dma_rec = [&](int slot, int s) __attribute__((always_inline)) {
-        const float* rec = a.coef + ((size_t)s * nC + c) * kRecStride + kG_Inv;
+    auto dma_rec = [&](int slot, const float* coef, int s) __attribute__((always_inline)) {
+        const float* rec = coef + ((size_t)s * nC + c) * kRecStride + kG_Inv;
 #pragma unroll
         for (int p = 0; p < kRecFwdPad / 256; ++p) {
             const int f = p * 64 + lane;
-            if (f < kRecFwd / 4) lds_dma16_s(rec + p * 256, 16u * lane, ring + (size_t)slot * kRecFwdPad + p * 256);
+            if (f < kRecFwd / 4) lds_dma16_a(rec + p * 256, 16u * lane, ring_lds + ((unsigned)slot * kRecFwdPad + p * 256u) * 4u);
         }
-    };
-    // v <- sum_j M[c][j] v_j over the channels of my sample: planes through the waves' images
-    auto mix = [&](float (&v)[M]) __attribute__((always_inline)) {
-        image_put<M>(T, l, hf, v);
-        __syncthreads();
-        float acc[M];
-#pragma unroll
-        for (int k = 0; k < M; ++k) acc[k] = 0.f;
-#pragma unroll
-        for (int j = 0; j < kSmallMaxC; ++j) {
-            if (j < nC) {
-                float o[M];
-                image_get<M>(imgs + (size_t)j * kImage, l, hf, o);
-#pragma unroll
-                for (int k = 0; k < M; ++k) acc[k] = fmaf(mrow[j], o[k], acc[k]);
-            }
-        }
-        __syncthreads();                                                  // everyone has read: the images are free again
-#pragma unroll
-        for (int k = 0; k < M; ++k) v[k] = acc[k];
     };
 
     int cur = 0;
-    dma_rec(0, 0);
-    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
-        float v[M];
-        small_load<N, 0, IO>(u, b, nC, c, lane, l, hf, T, v);
-        for (int k = 0; k < a.K; ++k) {
-            if (a.mode == 1) mix(v);                                      // cifar10.py:91
-            sfor<0, SPS>([&](auto SI) __attribute__((always_inline)) {
-                constexpr int si = decltype(SI)::value;
-                constexpr int AX = (si == 1) ? PDE_AXIS_Y : PDE_AXIS_X;   // Strang x,y,x / Lie x,y
-                const int s = k * SPS + si;
-                dma_wait_all();                                           // my record s has landed (wave-private ring)
-                __builtin_amdgcn_wave_barrier();
-                int sn = s + 1;
-                if (sn == S) sn = 0;                                      // first record of my next sample
-                if (sn != 0 || b + (int)gridDim.x < a.B) dma_rec(cur ^ 1, sn);
-                const float* rec = ring + (size_t)cur * kRecFwdPad;
-                if (AX == PDE_AXIS_Y) relayout<N, 0>(v, T, l, hf);
-                solve_fwd<M, 1>(v, rec, l, hf);
-                if (AX == PDE_AXIS_Y) relayout<N, 0>(v, T, l, hf);
-                if (a.ckpt != nullptr && si < SPS - 1 && ck_bit(a.ck, si)) {        // backward pre-pass: park this state
-                    float* slot = a.ckpt + ((size_t)k * a.nck + ck_slot(a.ck, si)) * tens;
-                    small_store<N, 0, float>(slot, b, nC, c, lane, l, hf, T, v);
-                }
-                cur ^= 1;
-            });
-            if (st != nullptr) {                                          // the step's sweep output, for the backward
-                small_store<N, 0, IO>(st + (size_t)k * tens, b, nC, c, lane, l, hf, T, v);
-                if (sizeof(IO) < 4) {                                     // go on from what the backward will read
+    dma_rec(0, small_layer(0)->coef, 0);
+    for (int li = 0; li < a.L; ++li) {
+        const ConstLayer Lp = small_layer(li);
+        const float* coef = Lp->coef;
+        const float* Mp = Lp->M;
+        const float* skp = Lp->skip_w;
+        IO* st = static_cast<IO*>(Lp->states);
+        float* ckpt = Lp->ckpt;
+        const unsigned long long ck[2] = {Lp->ck[0], Lp->ck[1]};
+        const int nck = Lp->nck, K = Lp->K, mode = Lp->mode, S = K * SPS;
+        const float* wpp = Lp->wp;
+        const float wl = wpp ? *wpp : Lp->w;
+        const bool last_layer = li + 1 == a.L;
+        const float* coef_next = last_layer ? small_layer(0)->coef : small_layer(li + 1)->coef;
+        float mrow[kSmallMaxC];                                           // my row of the operator
 #pragma unroll
-                    for (int q = 0; q < M; ++q) v[q] = round_io<IO>(v[q]);
+        for (int j = 0; j < kSmallMaxC; ++j) mrow[j] = (j < nC) ? Mp[c * nC + j] : 0.f;
+        const float sk = skp ? sigmoid_f(*skp) : 0.f;
+        // v <- sum_j M[c][j] v_j over the channels of my sample: planes through the waves' images
+        auto mix = [&](float (&v)[M]) __attribute__((always_inline)) {
+            image_put<M>(T, l, hf, v);
+            __syncthreads();
+            float acc[M];
+#pragma unroll
+            for (int k = 0; k < M; ++k) acc[k] = 0.f;
+#pragma unroll
+            for (int j = 0; j < kSmallMaxC; ++j) {
+                if (j < nC) {
+                    float o[M];
+                    image_get<M>(imgs + (size_t)j * kImage, l, hf, o);
+#pragma unroll
+                    for (int k = 0; k < M; ++k) acc[k] = fmaf(mrow[j], o[k], acc[k]);
                 }
             }
-            if (a.mode == 2) mix(v);                                      // SVHN.py:71
-        }
-        if (y != nullptr) {
-            if (a.skip_w != nullptr) {                                    // SVHN.py:74  sigmoid(w) u0 + (1 - sigmoid(w)) u
-                float u0[M];
-                small_load<N, 0, IO>(u, b, nC, c, lane, l, hf, T, u0);
+            __syncthreads();                                              // everyone has read: the images are free again
 #pragma unroll
-                for (int q = 0; q < M; ++q) v[q] = sk * u0[q] + (1.0f - sk) * v[q];
+            for (int k = 0; k < M; ++k) v[k] = acc[k];
+        };
+
+        for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+            const bool last_sample = b + (int)gridDim.x >= a.B;
+            float v[M], u0[M];
+            small_load<N, 0, IO>(u, b, nC, c, lane, l, hf, T, u0);
+#pragma unroll
+            for (int q = 0; q < M; ++q) v[q] = u0[q];
+            for (int k = 0; k < K; ++k) {
+                if (mode == 1) mix(v);                                    // cifar10.py:91
+                sfor<0, SPS>([&](auto SI) __attribute__((always_inline)) {
+                    constexpr int si = decltype(SI)::value;
+                    constexpr int AX = (si == 1) ? PDE_AXIS_Y : PDE_AXIS_X;   // Strang x,y,x / Lie x,y
+                    const int s = k * SPS + si;
+                    dma_wait_all();                                       // my record s has landed (wave-private ring)
+                    __builtin_amdgcn_wave_barrier();
+                    // next record: of this sample, of my next sample, or of the next layer's first sample
+                    if (s + 1 < S) dma_rec(cur ^ 1, coef, s + 1);
+                    else if (!last_sample) dma_rec(cur ^ 1, coef, 0);
+                    else if (!last_layer) dma_rec(cur ^ 1, coef_next, 0);
+                    const float* rec = ring + (size_t)cur * kRecFwdPad;
+                    if (AX == PDE_AXIS_Y) relayout<N, 0>(v, T, l, hf);
+                    solve_fwd<M, 1>(v, rec, l, hf);
+                    if (AX == PDE_AXIS_Y) relayout<N, 0>(v, T, l, hf);
+                    if (ckpt != nullptr && si < SPS - 1 && ck_bit(ck, si)) {          // backward pre-pass: park this state
+                        float* slot = ckpt + ((size_t)k * nck + ck_slot(ck, si)) * tens;
+                        small_store<N, 0, float>(slot, b, nC, c, lane, l, hf, T, v);
+                    }
+                    cur ^= 1;
+                });
+                if (st != nullptr) {                                      // the step's sweep output, for the backward
+                    small_store<N, 0, IO>(st + (size_t)k * tens, b, nC, c, lane, l, hf, T, v);
+                    if (sizeof(IO) < 4) {                                 // go on from what the backward will read
+#pragma unroll
+                        for (int q = 0; q < M; ++q) v[q] = round_io<IO>(v[q]);
+                    }
+                }
+                if (mode == 2) mix(v);                                    // SVHN.py:71
             }
-            small_store<N, 0, IO>(y, b, nC, c, lane, l, hf, T, v);
+            if (y != nullptr) {
+                if (skp != nullptr) {                                     // SVHN.py:74  sigmoid(w) u0 + (1 - sigmoid(w)) u
+#pragma unroll
+                    for (int q = 0; q < M; ++q) v[q] = sk * u0[q] + (1.0f - sk) * v[q];
+                }
+                if (a.L > 1) {                                            // out = sum_i w_i y_i: my own earlier store, re-read
+                    if (li > 0) {
+                        float o[M];
+                        small_load<N, 0, IO>(y, b, nC, c, lane, l, hf, T, o);
+#pragma unroll
+                        for (int q = 0; q < M; ++q) v[q] = fmaf(wl, v[q], o[q]);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < M; ++q) v[q] = wl * v[q];
+                    }
+                }
+                small_store<N, 0, IO>(y, b, nC, c, lane, l, hf, T, v);
+            }
         }
     }
     dma_wait_all();
@@ -221,8 +269,9 @@ __global__ __launch_bounds__(64 * kSmallMaxC) void adi_small_bwd_kernel(SmallArg
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, c = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hf = lane >> 5, l = lane & 31;
-    const int nC = a.C, S = a.K * SPS;
+    const int nC = a.C;
     float* ring = smem + (size_t)c * 2 * RECP;                            // wave-private [2][RECP]
+    const unsigned ring_lds = lds_byte_address(smem) + (unsigned)c * 2u * RECP * 4u;
     float* imgR = smem + (size_t)nC * 2 * RECP;                           // [C][kImage]: adjoints (also my re-layout image)
     float* imgX = imgR + (size_t)nC * kImage;                             // [C][kImage]: states
     float* T = imgR + (size_t)c * kImage;
@@ -230,146 +279,190 @@ __global__ __launch_bounds__(64 * kSmallMaxC) void adi_small_bwd_kernel(SmallArg
     for (int e = lane; e < kImage; e += 64) { T[e] = 0.f; TX[e] = 0.f; }
     const IO* u = static_cast<const IO*>(a.u);
     const IO* gy = static_cast<const IO*>(a.gy);
-    const IO* st = static_cast<const IO*>(a.states);
     IO* gu = static_cast<IO*>(a.out);
     const size_t tens = (size_t)a.B * nC * N * N;
-    const bool masked = as_const(a.varying)[c] != 0;                      // wave-uniform: my channel's clamp mask moves in time
-    float mrow[kSmallMaxC], mcol[kSmallMaxC];
-#pragma unroll
-    for (int j = 0; j < kSmallMaxC; ++j) {
-        mrow[j] = (j < nC) ? a.M[c * nC + j] : 0.f;
-        mcol[j] = (j < nC) ? a.M[j * nC + c] : 0.f;
-    }
-    const float sk = a.skip_w ? sigmoid_f(*a.skip_w) : 0.f;
+    const float live = (l < N) ? 1.0f : 0.0f;                             // idle lanes (N < 32) carry no data
 
-    float Ax[M], Tx[M], Ay[M], Ty[M], gm[kSmallMaxC], gskip = 0.f;
-#pragma unroll
-    for (int k = 0; k < M; ++k) Ax[k] = Tx[k] = Ay[k] = Ty[k] = 0.f;
-#pragma unroll
-    for (int j = 0; j < kSmallMaxC; ++j) gm[j] = 0.f;
-
-    auto dma_rec = [&](int slot, int s) __attribute__((always_inline)) {
-        const float* rec = a.coef + ((size_t)s * nC + c) * kRecStride + kBwdOff;
+    auto dma_rec = [&](int slot, const float* coef, int s) __attribute__((always_inline)) {
+        const float* rec = coef + ((size_t)s * nC + c) * kRecStride + kBwdOff;
 #pragma unroll
         for (int p = 0; p < RECP / 256; ++p) {
             const int f = p * 64 + lane;
-            if (f < kRecBwd / 4) lds_dma16_s(rec + p * 256, 16u * lane, ring + (size_t)slot * RECP + p * 256);
+            if (f < kRecBwd / 4) lds_dma16_a(rec + p * 256, 16u * lane, ring_lds + ((unsigned)slot * RECP + p * 256u) * 4u);
         }
-    };
-    // adjoint of v = M w at a step boundary: r holds dL/dv (my channel), xw the operator's input w (my channel):
-    //   gM[c][j] += sum r * w_j,   r <- sum_i M[i][c] r_i
-    auto mix_adjoint = [&](float (&r)[M], const float (&xw)[M], bool skip_term, const float (&gsk)[M], int b)
-                           __attribute__((always_inline)) {
-        image_put<M>(T, l, hf, r);
-        image_put<M>(TX, l, hf, xw);
-        __syncthreads();
-        const float live = (l < N) ? 1.0f : 0.0f;                        // idle lanes (N < 32) carry no data
-        float racc[M], vfull[M];
-#pragma unroll
-        for (int k = 0; k < M; ++k) { racc[k] = 0.f; vfull[k] = 0.f; }
-#pragma unroll
-        for (int j = 0; j < kSmallMaxC; ++j) {
-            if (j < nC) {
-                float o[M], w[M];
-                image_get<M>(imgR + (size_t)j * kImage, l, hf, o);
-                image_get<M>(imgX + (size_t)j * kImage, l, hf, w);
-                float d = 0.f;
-#pragma unroll
-                for (int k = 0; k < M; ++k) {
-                    racc[k] = fmaf(mcol[j], o[k], racc[k]);
-                    d = fmaf(r[k], w[k], d);
-                    vfull[k] = fmaf(mrow[j], w[k], vfull[k]);             // the operator's output, recomputed (skip term)
-                }
-                gm[j] = fmaf(live, d, gm[j]);
-            }
-        }
-        __syncthreads();
-        if (skip_term) {                                                  // d/dw of sigmoid(w) u0 + (1 - sigmoid(w)) b_K
-            float u0[M];
-            small_load<N, 0, IO>(u, b, nC, c, lane, l, hf, T, u0);
-#pragma unroll
-            for (int k = 0; k < M; ++k) gskip = fmaf(live * gsk[k], u0[k] - vfull[k], gskip);
-        }
-#pragma unroll
-        for (int k = 0; k < M; ++k) r[k] = racc[k];
     };
 
     int cur = 0;
-    dma_rec(0, S - 1);
-    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
-        float r[M], x[M], gsk[M];
-        small_load<N, 0, IO>(gy, b, nC, c, lane, l, hf, T, r);
+    dma_rec(0, small_layer(0)->coef, small_layer(0)->K * SPS - 1);
+    for (int li = 0; li < a.L; ++li) {
+        const ConstLayer Lp = small_layer(li);
+        const float* coef = Lp->coef;
+        const SweepTab* tabs = Lp->tabs;
+        const float* Mp = Lp->M;
+        const float* skp = Lp->skip_w;
+        const IO* st = static_cast<const IO*>(Lp->states);
+        const IO* gys = static_cast<const IO*>(Lp->gys);
+        const float* ckpt = Lp->ckpt;
+        const unsigned long long ck[2] = {Lp->ck[0], Lp->ck[1]};
+        const int nck = Lp->nck, K = Lp->K, mode = Lp->mode, S = K * SPS, smooth = Lp->smooth3;
+        const float* wpp = Lp->wp;
+        const float wl = wpp ? *wpp : Lp->w, step_scale = Lp->step_scale;
+        const bool last_layer = li + 1 == a.L;
+        const ConstLayer Ln = small_layer(last_layer ? 0 : li + 1);
+        const float* coef_next = Ln->coef;
+        const int s_next = Ln->K * SPS - 1;
+        const bool masked = as_const(Lp->varying)[c] != 0;                // wave-uniform: my channel's clamp mask moves in time
+        float mrow[kSmallMaxC], mcol[kSmallMaxC];
 #pragma unroll
-        for (int k = 0; k < M; ++k) { gsk[k] = sk * r[k]; r[k] = (1.0f - sk) * r[k]; }     // sk = 0 without a skip blend
-        if (a.mode == 1) small_load<N, 0, IO>(st + (size_t)(a.K - 1) * tens, b, nC, c, lane, l, hf, TX, x);
-        for (int k = a.K - 1; k >= 0; --k) {
-            if (a.mode == 2) {                                            // SVHN: the coupling came after the sweeps
-                small_load<N, 0, IO>(st + (size_t)k * tens, b, nC, c, lane, l, hf, TX, x);
-                mix_adjoint(r, x, a.skip_w != nullptr && k == a.K - 1, gsk, b);
+        for (int j = 0; j < kSmallMaxC; ++j) {
+            mrow[j] = (j < nC) ? Mp[c * nC + j] : 0.f;
+            mcol[j] = (j < nC) ? Mp[j * nC + c] : 0.f;
+        }
+        const float sk = skp ? sigmoid_f(*skp) : 0.f;
+
+        float Ax[M], Tx[M], Ay[M], Ty[M], gm[kSmallMaxC], gskip = 0.f, wsum = 0.f;
+#pragma unroll
+        for (int k = 0; k < M; ++k) Ax[k] = Tx[k] = Ay[k] = Ty[k] = 0.f;
+#pragma unroll
+        for (int j = 0; j < kSmallMaxC; ++j) gm[j] = 0.f;
+
+        // adjoint of v = M w at a step boundary: r holds dL/dv (my channel), xw the operator's input w (my channel):
+        //   gM[c][j] += sum r * w_j,   r <- sum_i M[i][c] r_i
+        auto mix_adjoint = [&](float (&r)[M], const float (&xw)[M], bool skip_term, const float (&gsk)[M], int b)
+                               __attribute__((always_inline)) {
+            image_put<M>(T, l, hf, r);
+            image_put<M>(TX, l, hf, xw);
+            __syncthreads();
+            float racc[M], vfull[M];
+#pragma unroll
+            for (int k = 0; k < M; ++k) { racc[k] = 0.f; vfull[k] = 0.f; }
+#pragma unroll
+            for (int j = 0; j < kSmallMaxC; ++j) {
+                if (j < nC) {
+                    float o[M], w[M];
+                    image_get<M>(imgR + (size_t)j * kImage, l, hf, o);
+                    image_get<M>(imgX + (size_t)j * kImage, l, hf, w);
+                    float d = 0.f;
+#pragma unroll
+                    for (int k = 0; k < M; ++k) {
+                        racc[k] = fmaf(mcol[j], o[k], racc[k]);
+                        d = fmaf(r[k], w[k], d);
+                        vfull[k] = fmaf(mrow[j], w[k], vfull[k]);         // the operator's output, recomputed (skip term)
+                    }
+                    gm[j] = fmaf(live, d, gm[j]);
+                }
             }
-            const ConstTab tab = as_const(a.tabs + k);
-            sfor<0, SPS>([&](auto SI) __attribute__((always_inline)) {
-                constexpr int si = SPS - 1 - decltype(SI)::value;         // newest sweep of the step first
-                constexpr int AX = (si == 1) ? PDE_AXIS_Y : PDE_AXIS_X;
-                const int s = k * SPS + si;
-                dma_wait_all();
-                __builtin_amdgcn_wave_barrier();
-                int sn = s - 1;
-                if (sn < 0) sn = S - 1;                                   // newest record of my next sample
-                if (sn != S - 1 || b + (int)gridDim.x < a.B) dma_rec(cur ^ 1, sn);
-                const float* rec = ring + (size_t)cur * RECP;
-                const float* recg = a.coef + ((size_t)s * nC + c) * kRecStride + kBwdOff;     // mask image: read from memory
-                const float tau = (si == 0) ? tab->dts[0] : (si == 1 ? tab->dts[1] : tab->t_last[0]);
-                if (AX == PDE_AXIS_Y) {
-                    if (masked) small_adj_sweep<N, PDE_AXIS_Y, true>(r, x, Ay, Ty, rec, recg, tau, T, l, hf, a.smooth3);
-                    else small_adj_sweep<N, PDE_AXIS_Y, false>(r, x, Ay, Ty, rec, recg, tau, T, l, hf, a.smooth3);
-                } else {
-                    if (masked) small_adj_sweep<N, PDE_AXIS_X, true>(r, x, Ax, Tx, rec, recg, tau, T, l, hf, a.smooth3);
-                    else small_adj_sweep<N, PDE_AXIS_X, false>(r, x, Ax, Tx, rec, recg, tau, T, l, hf, a.smooth3);
-                }
-                // x is the rebuilt state after sweep si-1 of this step; take the checkpoint instead if there is one
-                if (si > 0 && a.ckpt != nullptr && ck_bit(a.ck, si - 1)) {
-                    const float* slot = a.ckpt + ((size_t)k * a.nck + ck_slot(a.ck, si - 1)) * tens;
-                    small_load<N, 0, float>(slot, b, nC, c, lane, l, hf, TX, x);
-                    const float sc = tab->ysc[si - 1];
+            __syncthreads();
+            if (skip_term) {                                              // d/dw of sigmoid(w) u0 + (1 - sigmoid(w)) b_K
+                float u0[M];
+                small_load<N, 0, IO>(u, b, nC, c, lane, l, hf, T, u0);
 #pragma unroll
-                    for (int q = 0; q < M; ++q) x[q] *= sc;
-                }
-                cur ^= 1;
-            });
+                for (int k = 0; k < M; ++k) gskip = fmaf(live * gsk[k], u0[k] - vfull[k], gskip);
+            }
 #pragma unroll
-            for (int q = 0; q < M; ++q) r[q] *= a.step_scale;            // the (1+eps) carried by every adjoint solve
-            if (a.mode == 1) {                                            // cifar10: the mixing came before the sweeps
-                if (k > 0) small_load<N, 0, IO>(st + (size_t)(k - 1) * tens, b, nC, c, lane, l, hf, TX, x);
-                else small_load<N, 0, IO>(u, b, nC, c, lane, l, hf, TX, x);
-                mix_adjoint(r, x, false, gsk, b);                         // x stays: it is the sweep output of step k-1
+            for (int k = 0; k < M; ++k) r[k] = racc[k];
+        };
+
+        for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+            const bool last_sample = b + (int)gridDim.x >= a.B;
+            float r[M], x[M], gsk[M], g0[M];
+            if (gy != nullptr) small_load<N, 0, IO>(gy, b, nC, c, lane, l, hf, T, g0);
+            else {
+#pragma unroll
+                for (int k = 0; k < M; ++k) g0[k] = 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < M; ++k) r[k] = wl * g0[k];                // out = sum_i w_i y_i
+            if (gys != nullptr) {                                         // ... plus what arrives at y_i itself
+                float gi[M];
+                small_load<N, 0, IO>(gys, b, nC, c, lane, l, hf, T, gi);
+#pragma unroll
+                for (int k = 0; k < M; ++k) r[k] += gi[k];
+            }
+#pragma unroll
+            for (int k = 0; k < M; ++k) { gsk[k] = sk * r[k]; r[k] = (1.0f - sk) * r[k]; }     // sk = 0 without a skip blend
+            if (mode == 1) {
+                small_load<N, 0, IO>(st + (size_t)(K - 1) * tens, b, nC, c, lane, l, hf, TX, x);   // = y_i
+#pragma unroll
+                for (int k = 0; k < M; ++k) wsum = fmaf(live * g0[k], x[k], wsum);              // d out / d w_i = y_i
+            }
+            for (int k = K - 1; k >= 0; --k) {
+                if (mode == 2) {                                          // SVHN: the coupling came after the sweeps
+                    small_load<N, 0, IO>(st + (size_t)k * tens, b, nC, c, lane, l, hf, TX, x);
+                    mix_adjoint(r, x, skp != nullptr && k == K - 1, gsk, b);
+                }
+                const ConstTab tab = as_const(tabs + k);
+                sfor<0, SPS>([&](auto SI) __attribute__((always_inline)) {
+                    constexpr int si = SPS - 1 - decltype(SI)::value;     // newest sweep of the step first
+                    constexpr int AX = (si == 1) ? PDE_AXIS_Y : PDE_AXIS_X;
+                    const int s = k * SPS + si;
+                    dma_wait_all();
+                    __builtin_amdgcn_wave_barrier();
+                    // next record: of this sample, of my next sample, or of the next layer's first sample
+                    if (s > 0) dma_rec(cur ^ 1, coef, s - 1);
+                    else if (!last_sample) dma_rec(cur ^ 1, coef, S - 1);
+                    else if (!last_layer) dma_rec(cur ^ 1, coef_next, s_next);
+                    const float* rec = ring + (size_t)cur * RECP;
+                    const float* recg = coef + ((size_t)s * nC + c) * kRecStride + kBwdOff;     // mask image: read from memory
+                    const float tau = (si == 0) ? tab->dts[0] : (si == 1 ? tab->dts[1] : tab->t_last[0]);
+                    if (AX == PDE_AXIS_Y) {
+                        if (masked) small_adj_sweep<N, PDE_AXIS_Y, true>(r, x, Ay, Ty, rec, recg, tau, T, l, hf, smooth);
+                        else small_adj_sweep<N, PDE_AXIS_Y, false>(r, x, Ay, Ty, rec, recg, tau, T, l, hf, smooth);
+                    } else {
+                        if (masked) small_adj_sweep<N, PDE_AXIS_X, true>(r, x, Ax, Tx, rec, recg, tau, T, l, hf, smooth);
+                        else small_adj_sweep<N, PDE_AXIS_X, false>(r, x, Ax, Tx, rec, recg, tau, T, l, hf, smooth);
+                    }
+                    // x is the rebuilt state after sweep si-1 of this step; take the checkpoint instead if there is one
+                    if (si > 0 && ckpt != nullptr && ck_bit(ck, si - 1)) {
+                        const float* slot = ckpt + ((size_t)k * nck + ck_slot(ck, si - 1)) * tens;
+                        small_load<N, 0, float>(slot, b, nC, c, lane, l, hf, TX, x);
+                        const float sc = tab->ysc[si - 1];
+#pragma unroll
+                        for (int q = 0; q < M; ++q) x[q] *= sc;
+                    }
+                    cur ^= 1;
+                });
+#pragma unroll
+                for (int q = 0; q < M; ++q) r[q] *= step_scale;          // the (1+eps) carried by every adjoint solve
+                if (mode == 1) {                                          // cifar10: the mixing came before the sweeps
+                    if (k > 0) small_load<N, 0, IO>(st + (size_t)(k - 1) * tens, b, nC, c, lane, l, hf, TX, x);
+                    else small_load<N, 0, IO>(u, b, nC, c, lane, l, hf, TX, x);
+                    mix_adjoint(r, x, false, gsk, b);                     // x stays: it is the sweep output of step k-1
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < M; ++q) r[q] += gsk[q];                  // the skip branch's share of dL/du
+            if (li > 0) {                                                 // gu = sum over the layers: my own earlier store
+                float o[M];
+                small_load<N, 0, IO>(gu, b, nC, c, lane, l, hf, T, o);
+#pragma unroll
+                for (int q = 0; q < M; ++q) r[q] += o[q];
+            }
+            small_store<N, 0, IO>(gu, b, nC, c, lane, l, hf, T, r);
+        }
+
+        // my channel's sums of this layer: this workgroup's slot of the partial buffers (one wave per channel: nothing
+        // to add up here)
+        float* dst = Lp->part + ((size_t)blockIdx.x * nC + c) * 4 * kImage + l * kLineStride + hf * kHalfPad;
+#pragma unroll
+        for (int arr = 0; arr < 4; ++arr) {
+#pragma unroll
+            for (int i = 0; i < (M + 3) / 4; ++i) {
+                float4 v4;
+                auto at = [&](int k) { return k < M ? ((arr == 0) ? Ax[k] : (arr == 1) ? Tx[k] : (arr == 2) ? Ay[k] : Ty[k]) : 0.f; };
+                v4.x = at(4 * i); v4.y = at(4 * i + 1); v4.z = at(4 * i + 2); v4.w = at(4 * i + 3);
+                *reinterpret_cast<float4*>(dst + arr * kImage + 4 * i) = v4;
             }
         }
+        float* gd = Lp->gm_part + ((size_t)blockIdx.x * nC + c) * kGmStride;
 #pragma unroll
-        for (int q = 0; q < M; ++q) r[q] += gsk[q];                      // the skip branch's share of dL/du
-        small_store<N, 0, IO>(gu, b, nC, c, lane, l, hf, T, r);
+        for (int j = 0; j < kGmStride; ++j) {
+            float v = (j < kSmallMaxC) ? gm[j] : (j == kSmallMaxC ? gskip : wsum);
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) gd[j] = v;
+        }
     }
     dma_wait_all();
-
-    // my channel's sums: this workgroup's slot of the partial buffers (one wave per channel: nothing to add up here)
-    float* dst = a.part + ((size_t)blockIdx.x * nC + c) * 4 * kImage + l * kLineStride + hf * kHalfPad;
-#pragma unroll
-    for (int arr = 0; arr < 4; ++arr) {
-#pragma unroll
-        for (int i = 0; i < (M + 3) / 4; ++i) {
-            float4 v4;
-            auto at = [&](int k) { return k < M ? ((arr == 0) ? Ax[k] : (arr == 1) ? Tx[k] : (arr == 2) ? Ay[k] : Ty[k]) : 0.f; };
-            v4.x = at(4 * i); v4.y = at(4 * i + 1); v4.z = at(4 * i + 2); v4.w = at(4 * i + 3);
-            *reinterpret_cast<float4*>(dst + arr * kImage + 4 * i) = v4;
-        }
-    }
-    float* gd = a.gm_part + ((size_t)blockIdx.x * nC + c) * (kSmallMaxC + 1);
-#pragma unroll
-    for (int j = 0; j <= kSmallMaxC; ++j) {
-        float v = (j < kSmallMaxC) ? gm[j] : gskip;
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        if (lane == 0) gd[j] = v;
-    }
 }
 
 template <int N, typename IO>

@@ -14,7 +14,7 @@ import torch
 
 from . import _lib as L
 
-__all__ = ["Sweep", "adi_schedule", "adi_diffuse", "adi_diffuse_mixed", "adi_diffuse_small", "adi_small_supported", "plan_checkpoints", "kappa_max_async", "channel_mix", "skip_blend", "explicit5_step", "jacobi_diffuse",
+__all__ = ["Sweep", "adi_schedule", "adi_diffuse", "adi_diffuse_mixed", "adi_diffuse_small", "adi_small_supported", "adi_diffuse_multi", "plan_checkpoints", "kappa_max_async", "channel_mix", "skip_blend", "explicit5_step", "jacobi_diffuse",
            "timing_enable", "timing_read"]
 
 
@@ -380,6 +380,128 @@ class _AdiSmallFn(torch.autograd.Function):
         gp = [g.reshape(s) for g, s in zip(gp, ctx.param_shapes)]
         gskip = None if sw is None else gsw.to(ctx.skip_meta[0]).reshape(ctx.skip_meta[1])
         return (gu, *gp, gM.to(ctx.M_dtype), gskip, None, None, None, None, None, None, None)
+
+
+class _AdiMultiFn(torch.autograd.Function):
+    """Several mixing-first layers (cifar10.EnhancedDiffusionLayer / cifar_2version.LearnableDiffusionLayer, C <= 4)
+    on the SAME input in one launch per pass (pde_adi_multi_*): cifar10.py:272-280, cifar_2version.py:287-288.
+    Returns (sum_i w_i y_i, y_1, ..., y_L); the y_i are the last sweep outputs the kernel keeps anyway."""
+
+    @staticmethod
+    def forward(ctx, u, weights, specs, *flat):
+        lib = L.load()
+        nl = len(specs)
+        _require_cuda(u, weights, *flat)
+        B, Cc, N, _ = u.shape
+        if u.dtype not in (torch.float32, torch.bfloat16):
+            u = u.float()
+        u = u.contiguous()
+        need_grad = any(ctx.needs_input_grad)
+        ctx.set_materialize_grads(False)
+        wdev = None if weights is None else weights.detach().to(torch.float32).contiguous()   # read by the kernels on the device
+        arr = (L.PdeSmallLayer * nl)()
+        keep, descs, per = [], [], []
+        for i, (steps, smooth3, clamp_max, eps) in enumerate(specs):
+            ab, bb, asl, bsl, M = flat[5 * i:5 * i + 5]
+            sps, K = len(steps[0]), len(steps)
+            sweeps = tuple(s for st in steps for s in st)
+            p = [_as_chw(t, Cc, N) for t in (ab, bb, asl, bsl)]
+            Mf = M.detach().to(torch.float32).contiguous()
+            d = _make_desc(B, Cc, N, _io_dtype(u), sweeps, smooth3, clamp_max, eps)
+            sws = _workspace(lib.pde_adi_steps_workspace_bytes(C.byref(d), sps), u.device)
+            states = torch.empty((K,) + tuple(u.shape), dtype=u.dtype, device=u.device)
+            kdev = torch.empty(len(sweeps), dtype=torch.float32, device=u.device) if need_grad else None
+            host = torch.empty(len(sweeps), dtype=torch.float32, pin_memory=True) if need_grad else None
+            a = arr[i]
+            a.desc, a.sweeps_per_step, a.mode = C.pointer(d), sps, 1
+            a.M = Mf.data_ptr()
+            a.alpha_base, a.beta_base, a.alpha_slope, a.beta_slope = (t.data_ptr() for t in p)
+            a.weight = 0.0
+            a.weight_ptr = None if wdev is None else wdev.data_ptr() + 4 * i
+            a.states = states.data_ptr()
+            a.steps_workspace, a.steps_workspace_bytes = sws.data_ptr(), sws.numel()
+            a.kappa_max = kdev.data_ptr() if kdev is not None else None
+            a.kappa_max_host = host.data_ptr() if host is not None else None
+            keep.append((p, Mf, sws, states, kdev, host))
+            descs.append(d)
+            per.append((sps, K, [t.shape for t in (ab, bb, asl, bsl)], M.dtype))
+        out = torch.empty_like(u)
+        with torch.cuda.device(u.device):
+            ev = None
+            if need_grad:
+                ev = torch.cuda.Event()
+                ev.record()
+            L.check(lib.pde_adi_multi_forward(nl, arr, _ptr(u), _ptr(out), C.c_void_p(ev.cuda_event if ev is not None else 0),
+                                              _stream()), "pde_adi_multi_forward")
+        ctx.keep, ctx.descs, ctx.per, ctx.ev, ctx.u, ctx.wdev = keep, descs, per, ev, u, wdev
+        ctx.has_w = weights is not None
+        ys = [k[3][-1] for k in keep]                      # the last sweep output of every layer
+        return (out, *ys)
+
+    @staticmethod
+    def backward(ctx, gout, *gys):
+        lib = L.load()
+        nl = len(ctx.per)
+        u = ctx.u
+        B, Cc, N, _ = u.shape
+        arr = (L.PdeSmallLayer * nl)()
+        ctx.ev.synchronize()
+        outs, hold = [], []
+        gout_c = None if gout is None else gout.to(u.dtype).contiguous()
+        for i in range(nl):
+            p, Mf, sws, states, kdev, host = ctx.keep[i]
+            sps, K, shapes, Mdt = ctx.per[i]
+            d = ctx.descs[i]
+            km = host.tolist()
+            bits = 0
+            for k in range(K):
+                bits |= plan_checkpoints(km[k * sps:(k + 1) * sps])
+            mask = (C.c_uint64 * 2)(bits & (2 ** 64 - 1), bits >> 64)
+            ws = _workspace(lib.pde_adi_small_backward_workspace_bytes(C.byref(d), sps, bin(bits).count("1")), u.device)
+            gp = [torch.empty_like(t) for t in p]
+            gM = torch.empty_like(Mf)
+            gw = torch.empty(1, dtype=torch.float32, device=u.device)
+            gyi = None if gys[i] is None else gys[i].to(u.dtype).contiguous()
+            a = arr[i]
+            a.desc, a.sweeps_per_step, a.mode = C.pointer(d), sps, 1
+            a.M = Mf.data_ptr()
+            a.alpha_base, a.beta_base, a.alpha_slope, a.beta_slope = (t.data_ptr() for t in p)
+            a.weight = 0.0
+            a.weight_ptr = None if ctx.wdev is None else ctx.wdev.data_ptr() + 4 * i
+            a.states = states.data_ptr()
+            a.steps_workspace, a.steps_workspace_bytes = sws.data_ptr(), sws.numel()
+            a.gys = gyi.data_ptr() if gyi is not None else None
+            a.ckpt_mask = mask
+            a.g_alpha_base, a.g_beta_base, a.g_alpha_slope, a.g_beta_slope = (t.data_ptr() for t in gp)
+            a.gM, a.g_weight = gM.data_ptr(), gw.data_ptr()
+            a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+            hold.append((mask, ws, gyi))
+            outs.append((gp, gM, gw, shapes, Mdt))
+        if gout_c is None and all(h[2] is None for h in hold):
+            raise L.PdeError("adi_diffuse_multi: no incoming gradient")
+        gu = torch.empty_like(u)
+        with torch.cuda.device(u.device):
+            L.check(lib.pde_adi_multi_backward(nl, arr, _ptr(gout_c), _ptr(u), _ptr(gu), _stream()), "pde_adi_multi_backward")
+        flat = []
+        for gp, gM, gw, shapes, Mdt in outs:
+            flat += [g.reshape(s) for g, s in zip(gp, shapes)] + [gM.to(Mdt)]
+        gweights = torch.cat([o[2] for o in outs]) if ctx.has_w else None
+        return (gu, gweights, None, *flat)
+
+
+def adi_diffuse_multi(u, layers, weights=None):
+    """Run several mixing-first layers on the same ``u`` in one launch per pass.
+
+    ``layers``: list of dicts with keys alpha_base, beta_base, alpha_time_coeff, beta_time_coeff, M, steps and
+    optionally smooth3, clamp_max, eps.  ``weights`` (L,): ``out = sum_i weights[i] * y_i`` (cifar10.py:277-280
+    without the attention gates); None: ``out`` is not meaningful.  Returns ``(out, [y_1 .. y_L])``."""
+    specs = tuple((tuple(tuple(st) for st in ly["steps"]), bool(ly.get("smooth3", False)), ly.get("clamp_max"),
+                   float(ly.get("eps", 1e-6))) for ly in layers)
+    flat = []
+    for ly in layers:
+        flat += [ly["alpha_base"], ly["beta_base"], ly["alpha_time_coeff"], ly["beta_time_coeff"], ly["M"]]
+    res = _AdiMultiFn.apply(u, weights, specs, *flat)
+    return res[0], list(res[1:])
 
 
 def adi_small_supported(u, steps, smooth3=False, clamp_max=None, eps=1e-6) -> bool:

@@ -200,6 +200,38 @@ int pde_adi_small_backward(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t
                            float* gM, float* g_skip_weight, const void* steps_workspace,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- K1, layers that share an input, in ONE launch per pass ------------------------
+ * cifar10.py:272-274 runs three EnhancedDiffusionLayers (5, 8 and 4 steps with their own dt/dx and their own
+ * parameters) on the same x and combines them with softmax weights (:277-280); cifar_2version.py:287-288 two.
+ * pde_adi_multi_forward runs up to 4 such layers (C <= 4, mode 1) inside one launch — every workgroup walks its
+ * samples through layer after layer — and writes out = sum_i weight_i * y_i; the y_i themselves are the last of
+ * each layer's `states`.  One layer with weight 1 is pde_adi_small_forward.
+ * The backward takes gy = dL/dout and/or per layer gys = dL/dy_i, and gives gu = sum_i gu_i, every layer's
+ * parameter gradients, and g_weight = <gy, y_i>. */
+typedef struct PdeSmallLayer {
+    const PdeAdiDesc* desc;          /* the layer's own schedule; B, C, N, io_dtype equal across the layers  */
+    int32_t sweeps_per_step;         /* equal across the layers (all Strang or all Lie)                       */
+    int32_t mode;                    /* 1 | 2 as in pde_adi_mixed_forward; several layers: 1 only             */
+    const float* M;                  /* (C,C)                                                                  */
+    const float* skip_weight;        /* NULL | device scalar (mode 2)                                          */
+    const float* alpha_base; const float* beta_base; const float* alpha_slope; const float* beta_slope;
+    float weight;                    /* weight_i ...                                                           */
+    const float* weight_ptr;         /* ... or, when not NULL, a device scalar holding it (no host round trip)  */
+    void* states;                    /* K_i tensors (forward: NULL = inference)                                */
+    void* steps_workspace; size_t steps_workspace_bytes;     /* pde_adi_steps_workspace_bytes(desc, sps)      */
+    float* kappa_max; float* kappa_max_host;                 /* optional, as in pde_adi_forward               */
+    /* backward only */
+    const void* gys;                 /* NULL | dL/dy_i                                                         */
+    const uint64_t* ckpt_mask;       /* relative to a step                                                     */
+    float* g_alpha_base; float* g_beta_base; float* g_alpha_slope; float* g_beta_slope;
+    float* gM; float* g_skip_weight; float* g_weight;        /* g_weight optional                              */
+    void* workspace; size_t workspace_bytes;                 /* pde_adi_small_backward_workspace_bytes()      */
+} PdeSmallLayer;
+int pde_adi_multi_forward(int32_t num_layers, const PdeSmallLayer* layers, const void* u, void* out,
+                          void* kappa_event, void* stream);
+int pde_adi_multi_backward(int32_t num_layers, const PdeSmallLayer* layers, const void* gy, const void* u,
+                           void* gu, void* stream);
+
 /* ---- channel operators ------------------------------------------ */
 
 /* out[b,i,p] = sum_j M[i,j] u[b,j,p]  — cifar10.py:65-72 apply_channel_mixing and

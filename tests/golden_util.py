@@ -10,11 +10,12 @@ import torch
 from oracle import pde_oracle as O
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+MODEL_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_models")   # the reference's MODELS around the layers
 
 
-def names(prefixes=None, f64=None):
+def names(prefixes=None, f64=None, directory=None):
     out = []
-    for p in sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))):
+    for p in sorted(glob.glob(os.path.join(directory or GOLDEN_DIR, "*.npz"))):
         n = os.path.basename(p)[:-4]
         if prefixes and not any(n.startswith(x) for x in prefixes):
             continue
@@ -25,8 +26,8 @@ def names(prefixes=None, f64=None):
 
 
 class Golden:
-    def __init__(self, name):
-        z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+    def __init__(self, name, directory=None):
+        z = np.load(os.path.join(directory or GOLDEN_DIR, name + ".npz"), allow_pickle=False)
         self.name = name
         self.meta = json.loads(bytes(z["meta"]).decode())
         self.dtype = getattr(torch, self.meta["dtype"])

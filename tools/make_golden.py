@@ -90,9 +90,68 @@ def _make(name, script, cls, ctor, B, g, dtype, tweak, u_fn, mod):
     _save(name, script, cls, ctor, layer, u, gy, dtype)
 
 
+def make_model(name, script, cls, ctor, shape, seed, tweak=None, out_index=0, eval_mode=True):
+    """A fixture of one of the reference's MODELS around the layers (tests/golden_models): same format, the output is
+    element ``out_index`` of what the module returns.  eval(): dropout off, batch norm on its running statistics."""
+    mod = ref_loader.load(script)
+    g = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    with ref_loader.quiet():
+        model = getattr(mod, cls)(**ctor)
+    if eval_mode:
+        model.eval()
+    if tweak is not None:
+        tweak(model, g)
+    u = torch.randn(*shape, generator=g)
+
+    def fwd(x):
+        y = model(x)
+        return y[out_index] if isinstance(y, (tuple, list)) else y
+    y0 = fwd(u)
+    gy = torch.randn(y0.shape, generator=g)
+
+    class W(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.m = model
+
+        def forward(self, x):
+            return fwd(x)
+
+        def named_parameters(self, *a, **k):
+            return model.named_parameters(*a, **k)
+    global OUT
+    keep, OUT = OUT, os.path.join(os.path.dirname(HERE), "tests", "golden_models")
+    os.makedirs(OUT, exist_ok=True)
+    try:
+        _save(name, script, cls, ctor, W(), u, gy, torch.float32)
+    finally:
+        OUT = keep
+
+
+def models():
+    def live(m, g):
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                if n.endswith("alpha_base") or n.endswith("beta_base"):
+                    p.mul_(1 + 0.2 * torch.randn(p.shape, generator=g))
+                elif n.endswith("time_coeff"):
+                    p.copy_(0.3 * torch.randn(p.shape, generator=g))
+                elif n.endswith("channel_mixing"):
+                    p.copy_(torch.eye(p.shape[0]) + 0.1 * torch.randn(p.shape, generator=g))
+                elif n.endswith("combine_weights"):
+                    p.copy_(torch.tensor([0.2, 0.5, -0.1]))
+    # cifar10.MultiScaleExtractor: three PDE layers on one input + attention gates + softmax combination
+    make_model("model_cifar10_multiscale", "cifar10", "MultiScaleExtractor", {"input_size": 32, "channels": 3},
+               (3, 3, 32, 32), 81, tweak=live)
+    make_model("model_cifar10_multiscale_default", "cifar10", "MultiScaleExtractor", {"input_size": 32, "channels": 3},
+               (2, 3, 32, 32), 82)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     f32, f64 = torch.float32, torch.float64
+    models()
 
     # ---- mnist_test.DiffusionLayer ------------------------------------------------
     make("mnist_default", "mnist_test", "DiffusionLayer", {}, 3, 11)
@@ -221,4 +280,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "models":
+        models()
+    else:
+        main()

@@ -21,4 +21,27 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(20):
     step()
 torch.cuda.synchronize()
-print("three cifar10 layers (C=3, B=128) fwd+bwd: %.3f ms" % ((time.perf_counter() - t0) / 20 * 1e3))
+print("three cifar10 layers (C=3, B=128) fwd+bwd, one call per layer: %.3f ms" % ((time.perf_counter() - t0) / 20 * 1e3))
+w = torch.softmax(torch.zeros(3, device="cuda"), 0).requires_grad_(True)
+def step2():
+    for l in layers:
+        for p in l.parameters():
+            p.grad = None
+    x.grad = None
+    out, _ = P.diffuse_shared_input(layers, x, w)
+    out.backward(gy)
+for _ in range(5):
+    step2()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(50):
+    step2()
+torch.cuda.synchronize()
+print("the same three layers in ONE launch per pass (diffuse_shared_input, weighted sum in the kernel): %.3f ms"
+      % ((time.perf_counter() - t0) / 50 * 1e3))
+if os.environ.get("PDE_PROFILE_HOST"):
+    import cProfile, pstats
+    pr = cProfile.Profile(); pr.enable()
+    for _ in range(200):
+        step2()
+    torch.cuda.synchronize(); pr.disable()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(25)
