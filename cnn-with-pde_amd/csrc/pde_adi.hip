@@ -330,11 +330,14 @@ struct PgradArgs {
     int gm_blocks;
 };
 
+// One workgroup per (channel, sum): the four sums of a channel (A_x, T_x, A_y, T_y) each give exactly one output
+// (g_alpha_base, g_alpha_slope, g_beta_base, g_beta_slope), so they reduce independently — 4 C workgroups instead
+// of C (the whole-layer kernels for C <= 4 leave up to 1024 groups to add up: 3 workgroups took 44 us there).
 __global__ __launch_bounds__(1024) void adi_pgrad_kernel(PgradArgs a) {
-    __shared__ float sm[4][PDE_MAX_N][PDE_MAX_N + 1];
-    const int N = a.N, c = blockIdx.x;
+    __shared__ float sm[PDE_MAX_N][PDE_MAX_N + 1];
+    const int N = a.N;
     const int tid = threadIdx.x;
-    if (c == a.C) {                                   // (only launched when gm_part is given)
+    if ((int)blockIdx.x == 4 * a.C) {                 // (only launched when gm_part is given)
         if (tid < a.C * a.C) {
             const int i = tid / a.C, j = tid % a.C;
             float sum = 0.f;
@@ -354,75 +357,56 @@ __global__ __launch_bounds__(1024) void adi_pgrad_kernel(PgradArgs a) {
         }
         return;
     }
+    const int c = blockIdx.x >> 2, arr = blockIdx.x & 3, ax = arr >> 1;      // arr: 0 A_x, 1 T_x, 2 A_y, 3 T_y
     const int h = tid / N, w = tid % N;
     const bool act = tid < N * N;
     if (act) {
-        // fixed summation order (deterministic), four groups at a time so that 16 loads are in flight per thread:
-        // the whole-layer kernels for C <= 4 leave one group per workgroup (up to 1024), and a serial chain of
-        // G dependent loads took 140 us at G = 128
+        // fixed summation order (deterministic), eight groups at a time so that eight loads are in flight per thread
         const int e = h * kLineStride + half_pos(w, N);
         const size_t gs = (size_t)a.C * 4 * kImage;
-        const float* p0 = a.part + (size_t)c * 4 * kImage + e;
-        float s[4][4];
+        const float* p0 = a.part + ((size_t)c * 4 + arr) * kImage + e;
+        float s[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int arr = 0; arr < 4; ++arr) s[q][arr] = 0.f;
+        for (int q = 0; q < 8; ++q) s[q] = 0.f;
         int g = 0;
-        for (; g + 4 <= a.G; g += 4) {
+        for (; g + 8 <= a.G; g += 8) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int arr = 0; arr < 4; ++arr) s[q][arr] += p0[(size_t)(g + q) * gs + (size_t)arr * kImage];
+            for (int q = 0; q < 8; ++q) s[q] += p0[(size_t)(g + q) * gs];
         }
-        for (; g < a.G; ++g)
-#pragma unroll
-            for (int arr = 0; arr < 4; ++arr) s[0][arr] += p0[(size_t)g * gs + (size_t)arr * kImage];
-#pragma unroll
-        for (int arr = 0; arr < 4; ++arr) sm[arr][h][w] = (s[0][arr] + s[1][arr]) + (s[2][arr] + s[3][arr]);
+        for (; g < a.G; ++g) s[0] += p0[(size_t)g * gs];
+        sm[h][w] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     }
     __syncthreads();
     if (!act) return;
     const size_t off = ((size_t)c * N + h) * N + w;
-    for (int ax = 0; ax < 2; ++ax) {
-        const float wgt = -(ax == 0 ? a.wx : a.wy);
-        float gb, gs;
-        {
-            const float(*A)[PDE_MAX_N + 1] = sm[2 * ax];
-            const float(*Tm)[PDE_MAX_N + 1] = sm[2 * ax + 1];
-            if (a.varying[c]) {
-                const float f = a.smooth3 ? wgt * (1.0f / 3.0f) : wgt;
-                gb = A[h][w] * f;
-                gs = Tm[h][w] * f;
-            } else if (a.smooth3) {
-                // transpose of the replicate-padded 3-tap average along the solve axis:
-                // theta_bar_j = (1/3)(c_j q_j + q_{j-1} + q_{j+1}),  c_j = 2 at the two ends, else 1
-                const int i = (ax == 0) ? w : h;
-                auto at = [&](const float(*Q)[PDE_MAX_N + 1], int ii) { return (ax == 0) ? Q[h][ii] : Q[ii][w]; };
-                const float cj = (i == 0 || i == N - 1) ? 2.0f : 1.0f;
-                float sa = at(A, i) * cj, stt = at(Tm, i) * cj;
-                if (i > 0) { sa += at(A, i - 1); stt += at(Tm, i - 1); }
-                if (i < N - 1) { sa += at(A, i + 1); stt += at(Tm, i + 1); }
-                gb = sa * (1.0f / 3.0f) * wgt;
-                gs = stt * (1.0f / 3.0f) * wgt;
-            } else {
-                gb = A[h][w] * wgt;
-                gs = Tm[h][w] * wgt;
-            }
-        }
-        // clamp pass-through mask, the same for every sweep of a channel that gets here unflagged
-        if (!a.varying[c]) {
-            const float base = (ax == 0 ? a.ab : a.bb)[off];
-            const float slope = (ax == 0 ? a.as : a.bs)[off];
-            const float th = base + slope * a.t_first[ax];
-            const bool pass = (th >= a.eps) && (!a.has_max || th <= a.cmax);
-            if (!pass || !a.have_axis[ax]) { gb = 0.f; gs = 0.f; }
-        }
-        float* ob = (ax == 0) ? a.g_ab : a.g_bb;
-        float* os = (ax == 0) ? a.g_as : a.g_bs;
-        if (a.accumulate) { ob[off] += gb; os[off] += gs; }
-        else { ob[off] = gb; os[off] = gs; }
+    const float wgt = -(ax == 0 ? a.wx : a.wy);
+    float gv;
+    if (a.varying[c]) {
+        gv = sm[h][w] * (a.smooth3 ? wgt * (1.0f / 3.0f) : wgt);
+    } else if (a.smooth3) {
+        // transpose of the replicate-padded 3-tap average along the solve axis:
+        // theta_bar_j = (1/3)(c_j q_j + q_{j-1} + q_{j+1}),  c_j = 2 at the two ends, else 1
+        const int i = (ax == 0) ? w : h;
+        auto at = [&](int ii) { return (ax == 0) ? sm[h][ii] : sm[ii][w]; };
+        const float cj = (i == 0 || i == N - 1) ? 2.0f : 1.0f;
+        float sa = at(i) * cj;
+        if (i > 0) sa += at(i - 1);
+        if (i < N - 1) sa += at(i + 1);
+        gv = sa * (1.0f / 3.0f) * wgt;
+    } else {
+        gv = sm[h][w] * wgt;
     }
+    // clamp pass-through mask, the same for every sweep of a channel that gets here unflagged
+    if (!a.varying[c]) {
+        const float base = (ax == 0 ? a.ab : a.bb)[off];
+        const float slope = (ax == 0 ? a.as : a.bs)[off];
+        const float th = base + slope * a.t_first[ax];
+        const bool pass = (th >= a.eps) && (!a.has_max || th <= a.cmax);
+        if (!pass || !a.have_axis[ax]) gv = 0.f;
+    }
+    float* o = (arr == 0) ? a.g_ab : (arr == 1) ? a.g_as : (arr == 2) ? a.g_bb : a.g_bs;
+    if (a.accumulate) o[off] += gv;
+    else o[off] = gv;
 }
 
 // ------------------------------------------------------------------------------------
@@ -670,7 +654,7 @@ int launch_pgrad(const PdeAdiDesc* d, const AxisWeights& w, const float* alpha_b
     pa.wx = w.wgt[0] / (1.0f + d->eps); pa.wy = w.wgt[1] / (1.0f + d->eps);
     pa.t_first[0] = w.tfirst[0]; pa.t_first[1] = w.tfirst[1];
     pa.have_axis[0] = w.have[0]; pa.have_axis[1] = w.have[1];
-    hipLaunchKernelGGL(adi_pgrad_kernel, dim3(d->C + (gm_part ? 1 : 0)), dim3(1024), 0, st, pa);
+    hipLaunchKernelGGL(adi_pgrad_kernel, dim3(4 * d->C + (gm_part ? 1 : 0)), dim3(1024), 0, st, pa);
     return check_launch();
 }
 

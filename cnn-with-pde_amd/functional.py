@@ -15,7 +15,7 @@ import torch
 from . import _lib as L
 
 __all__ = ["Sweep", "adi_schedule", "adi_diffuse", "adi_diffuse_mixed", "adi_diffuse_small", "adi_small_supported", "adi_diffuse_multi", "plan_checkpoints", "kappa_max_async", "channel_mix", "skip_blend", "explicit5_step", "jacobi_diffuse",
-           "timing_enable", "timing_read"]
+           "timing_enable", "timing_read", "Schedule"]
 
 
 @dataclass(frozen=True)
@@ -25,6 +25,36 @@ class Sweep:
     delta: float     # dt/2 or dt
     h2: float        # dx**2 or dy**2
     t: float         # current_time at which alpha/beta are evaluated
+
+
+class _HashedTuple(tuple):
+    """A tuple whose hash is computed once: schedules are dictionary keys on every layer call (launch descriptors,
+    support checks), and hashing 30 frozen dataclasses costs more host time than a kernel launch."""
+
+    def __hash__(self):
+        h = self.__dict__.get("_h")
+        if h is None:
+            h = self.__dict__["_h"] = tuple.__hash__(self)
+        return h
+
+    def __eq__(self, other):
+        return self is other or tuple.__eq__(self, other)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+
+class Schedule(_HashedTuple):
+    """Per-step sweep tuples of one layer call; ``.flat`` is the same sweeps as one flat tuple."""
+
+    def __new__(cls, steps):
+        self = super().__new__(cls, (_HashedTuple(st) for st in steps))
+        self.flat = _HashedTuple(s for st in self for s in st)
+        return self
+
+
+def _as_schedule(steps) -> "Schedule":
+    return steps if isinstance(steps, Schedule) else Schedule(steps)
 
 
 def adi_schedule(dt: float, dx: float, dy: float, num_steps: int, split: str = "strang") -> List[List[Sweep]]:
@@ -75,7 +105,9 @@ _desc_cache = {}
 def _make_desc(B, Cc, N, io, sweeps: Sequence[Sweep], smooth3, clamp_max, eps) -> L.PdeAdiDesc:
     """The launch descriptor (read-only for the library).  Cached: filling ~100 ctypes fields costs more
     host time than the kernels of a small layer take on the device."""
-    key = (B, Cc, N, io, tuple(sweeps), bool(smooth3), clamp_max, float(eps))
+    if not isinstance(sweeps, tuple):
+        sweeps = tuple(sweeps)
+    key = (B, Cc, N, io, sweeps, bool(smooth3), clamp_max, float(eps))
     d = _desc_cache.get(key)
     if d is None:
         if len(_desc_cache) > 256:
@@ -103,6 +135,9 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 
 
 def _as_chw(p: torch.Tensor, Cc: int, N: int) -> torch.Tensor:
+    if p.dtype == torch.float32 and p.dim() == 3 and p.shape[0] == Cc and p.shape[1] == N and p.shape[2] == N \
+            and p.is_contiguous():
+        return p.detach()
     q = p.detach()
     if q.dim() == 2:
         q = q.unsqueeze(0)
@@ -135,7 +170,7 @@ def plan_checkpoints(kappa_max: Sequence[float], amax: float = CKPT_AMAX) -> int
 def kappa_max_async(u_like, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff, sweeps: Sequence[Sweep],
                     smooth3=False, clamp_max=None, eps=1e-6):
     """Launch the per-sweep max-coefficient kernel and an asynchronous copy to pinned host memory.
-    Returns (host_tensor, event); the values are valid once ``event.query()`` is True."""
+    Returns an object with ``.host`` / ``.event``; the values are valid once ``event.query()`` is True."""
     lib = L.load()
     _require_cuda(u_like, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff)
     B, Cc, N, _ = u_like.shape
@@ -148,16 +183,79 @@ def kappa_max_async(u_like, alpha_base, beta_base, alpha_time_coeff, beta_time_c
         host.copy_(kdev, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-    return host, ev
+    return _KmaxOwned(host, ev)
+
+
+#: entries of the per-device ring of (pinned buffer, event) pairs through which the per-sweep coefficient maxima reach
+#: the host; one entry is held from a forward to its backward, so this bounds the PDE-layer calls whose backward is
+#: still outstanding (raise it for models with more PDE layers than this in one graph)
+KMAX_RING = 256
+_kmax_rings = {}
+
+
+class _KmaxEntry:
+    __slots__ = ("host", "event", "gen")
 
 
 def _kmax_channel(n: int):
-    """Pinned host buffer and a created event for the early copy of the per-sweep coefficient maxima
-    (pde_adi_forward records the event itself, right behind the factorisation kernel)."""
-    host = torch.empty(n, dtype=torch.float32, pin_memory=True)
-    ev = torch.cuda.Event()
-    ev.record()                     # creates the underlying hipEvent_t; the library re-records it
-    return host, ev
+    """Pinned host buffer and an event for the early copy of the per-sweep coefficient maxima (pde_adi_forward copies
+    and records, right behind the factorisation kernel).  Creating a pinned tensor and an event per call costs more
+    host time than the launches of a small layer: they come from a ring, with a generation check against reuse
+    while a backward is still outstanding."""
+    dev = torch.cuda.current_device()
+    ring = _kmax_rings.get(dev)
+    if ring is None:
+        pool = torch.empty(KMAX_RING * L.PDE_MAX_SWEEPS * 4, dtype=torch.float32, pin_memory=True)
+        ring = _kmax_rings[dev] = {"next": 0, "entries": []}
+        for i in range(KMAX_RING):
+            e = _KmaxEntry()
+            e.host = pool[i * L.PDE_MAX_SWEEPS * 4:(i + 1) * L.PDE_MAX_SWEEPS * 4]
+            e.event = torch.cuda.Event()
+            e.event.record()            # creates the underlying hipEvent_t; the library re-records it
+            e.gen = 0
+            ring["entries"].append(e)
+    e = ring["entries"][ring["next"]]
+    ring["next"] = (ring["next"] + 1) % KMAX_RING
+    e.gen += 1
+    if n > e.host.numel():
+        raise L.PdeError(f"{n} coefficient maxima exceed the ring entry of {e.host.numel()}")
+    return _KmaxTicket(e, n)
+
+
+class _KmaxOwned:
+    """Coefficient maxima in a buffer of their own (kappa_max_async)."""
+    __slots__ = ("host", "event")
+
+    def __init__(self, host, event):
+        self.host, self.event = host, event
+
+
+class _KmaxTicket:
+    """One use of a ring entry: ``host`` / ``event`` as long as the entry has not been handed out again."""
+    __slots__ = ("entry", "gen", "n")
+
+    def __init__(self, entry, n):
+        self.entry, self.gen, self.n = entry, entry.gen, n
+
+    def _check(self):
+        if self.entry.gen != self.gen:
+            raise L.PdeError("the coefficient-maxima ring entry of this call was reused before its backward ran: "
+                             "more than functional.KMAX_RING PDE-layer calls are outstanding; raise KMAX_RING")
+
+    @property
+    def host(self):
+        self._check()
+        return self.entry.host[:self.n]
+
+    @property
+    def event(self):
+        self._check()
+        return self.entry.event
+
+    def wait(self):
+        """Values once the copy has landed (waits for the factorisation kernel only)."""
+        self.event.synchronize()
+        return self.host.tolist()
 
 
 class _AdiFn(torch.autograd.Function):
@@ -183,13 +281,13 @@ class _AdiFn(torch.autograd.Function):
             # per-sweep maximum coefficient (a by-product of the factorisation kernel): copied to pinned host
             # memory right behind that kernel, before the sweep launch, so whoever plans checkpoints from it
             # waits for the factorisation only
-            host, ev = _kmax_channel(len(sweeps)) if want_kmax else (None, None)
-            L.check(lib.pde_adi_forward(C.byref(d), _ptr(u), _ptr(y), *[_ptr(t) for t in p], _ptr(kdev), _ptr(host),
-                                        C.c_void_p(ev.cuda_event if ev is not None else 0),
+            tk = _kmax_channel(len(sweeps)) if want_kmax else None
+            L.check(lib.pde_adi_forward(C.byref(d), _ptr(u), _ptr(y), *[_ptr(t) for t in p], _ptr(kdev),
+                                        _ptr(tk.host if tk else None), C.c_void_p(tk.event.cuda_event if tk else 0),
                                         _ptr(ws), ws.numel(), _stream()), "pde_adi_forward")
-            ctx.kmax_host, ctx.kmax_event = host, ev
+            ctx.kmax = tk
             if want_kmax and kmax_sink is not None:
-                kmax_sink.append((host, ev))
+                kmax_sink.append(tk)
         ctx.fwd_ws = ws if need_grad else None       # factorisation reused by the backward
         ctx.save_for_backward(y, u if (need_grad and ckpt != 0) else None, *p)
         ctx.cfg = (sweeps, smooth3, clamp_max, eps, ckpt)
@@ -207,8 +305,7 @@ class _AdiFn(torch.autograd.Function):
         gu = torch.empty_like(y)
         gp = [torch.empty_like(t) for t in p]
         if ckpt == "auto":
-            ctx.kmax_event.synchronize()
-            bits = plan_checkpoints(ctx.kmax_host.tolist())
+            bits = plan_checkpoints(ctx.kmax.wait())
         else:
             bits = int(ckpt)
         mask = (C.c_uint64 * 2)(bits & (2 ** 64 - 1), bits >> 64)
@@ -254,15 +351,15 @@ class _AdiMixedFn(torch.autograd.Function):
         # states[k][0]: output of the step's first operator, states[k][1]: of its second (= input of step k+1)
         states = torch.empty((K, 2) + tuple(u.shape), dtype=u.dtype, device=u.device)
         with torch.cuda.device(u.device):
-            host, ev = _kmax_channel(len(sweeps)) if want_kmax else (None, None)
+            tk = _kmax_channel(len(sweeps)) if want_kmax else None
             L.check(lib.pde_adi_mixed_forward(C.byref(d), sps, 1 if mode == "pre" else 2, _ptr(u), _ptr(states), _ptr(Mf),
-                                              *[_ptr(t) for t in p], _ptr(kdev), _ptr(host),
-                                              C.c_void_p(ev.cuda_event if ev is not None else 0),
+                                              *[_ptr(t) for t in p], _ptr(kdev), _ptr(tk.host if tk else None),
+                                              C.c_void_p(tk.event.cuda_event if tk else 0),
                                               _ptr(sws), sws.numel(), _stream()),
                     "pde_adi_mixed_forward")
-            ctx.kmax_host, ctx.kmax_event = host, ev
+            ctx.kmax = tk
             if want_kmax and kmax_sink is not None:
-                kmax_sink.append((host, ev))
+                kmax_sink.append(tk)
         y = states[K - 1, 1]
         if need_grad:
             ctx.save_for_backward(u, states, Mf, *p)
@@ -282,8 +379,7 @@ class _AdiMixedFn(torch.autograd.Function):
         sweeps = tuple(s for st in steps for s in st)
         d = _make_desc(B, Cc, N, _io_dtype(u), sweeps, smooth3, clamp_max, eps)
         if ckpt == "auto":
-            ctx.kmax_event.synchronize()
-            km = ctx.kmax_host.tolist()
+            km = ctx.kmax.wait()
             bits = 0
             for k in range(K):                           # one step-local mask for every step: the union
                 bits |= plan_checkpoints(km[k * sps:(k + 1) * sps])
@@ -319,7 +415,7 @@ class _AdiSmallFn(torch.autograd.Function):
             u = u.float()
         u = u.contiguous()
         sps, K = len(steps[0]), len(steps)
-        sweeps = tuple(s for st in steps for s in st)
+        sweeps = steps.flat
         p = [_as_chw(t, Cc, N) for t in (ab, bb, asl, bsl)]
         Mf = M.detach().to(torch.float32).contiguous()
         sw = None if skip_weight is None else skip_weight.detach().to(torch.float32).reshape(1).contiguous()
@@ -331,14 +427,14 @@ class _AdiSmallFn(torch.autograd.Function):
         states = torch.empty((K,) + tuple(u.shape), dtype=u.dtype, device=u.device) if need_grad else None
         y = torch.empty_like(u)
         with torch.cuda.device(u.device):
-            host, ev = _kmax_channel(len(sweeps)) if want_kmax else (None, None)
+            tk = _kmax_channel(len(sweeps)) if want_kmax else None
             L.check(lib.pde_adi_small_forward(C.byref(d), sps, 1 if mode == "pre" else 2, _ptr(u), _ptr(y), _ptr(states),
-                                              _ptr(Mf), _ptr(sw), *[_ptr(t) for t in p], _ptr(kdev), _ptr(host),
-                                              C.c_void_p(ev.cuda_event if ev is not None else 0),
+                                              _ptr(Mf), _ptr(sw), *[_ptr(t) for t in p], _ptr(kdev),
+                                              _ptr(tk.host if tk else None), C.c_void_p(tk.event.cuda_event if tk else 0),
                                               _ptr(sws), sws.numel(), _stream()), "pde_adi_small_forward")
-            ctx.kmax_host, ctx.kmax_event = host, ev
+            ctx.kmax = tk
             if want_kmax and kmax_sink is not None:
-                kmax_sink.append((host, ev))
+                kmax_sink.append(tk)
         if need_grad:
             ctx.save_for_backward(u, states, Mf, sw, *p)
             ctx.sws = sws
@@ -355,11 +451,10 @@ class _AdiSmallFn(torch.autograd.Function):
         steps, mode, smooth3, clamp_max, eps, ckpt = ctx.cfg
         B, Cc, N, _ = u.shape
         sps, K = len(steps[0]), len(steps)
-        sweeps = tuple(s for st in steps for s in st)
+        sweeps = steps.flat
         d = _make_desc(B, Cc, N, _io_dtype(u), sweeps, smooth3, clamp_max, eps)
         if ckpt == "auto":
-            ctx.kmax_event.synchronize()
-            km = ctx.kmax_host.tolist()
+            km = ctx.kmax.wait()
             bits = 0
             for k in range(K):                           # one step-local mask for every step: the union
                 bits |= plan_checkpoints(km[k * sps:(k + 1) * sps])
@@ -404,14 +499,16 @@ class _AdiMultiFn(torch.autograd.Function):
         for i, (steps, smooth3, clamp_max, eps) in enumerate(specs):
             ab, bb, asl, bsl, M = flat[5 * i:5 * i + 5]
             sps, K = len(steps[0]), len(steps)
-            sweeps = tuple(s for st in steps for s in st)
+            sweeps = steps.flat
             p = [_as_chw(t, Cc, N) for t in (ab, bb, asl, bsl)]
             Mf = M.detach().to(torch.float32).contiguous()
             d = _make_desc(B, Cc, N, _io_dtype(u), sweeps, smooth3, clamp_max, eps)
             sws = _workspace(lib.pde_adi_steps_workspace_bytes(C.byref(d), sps), u.device)
             states = torch.empty((K,) + tuple(u.shape), dtype=u.dtype, device=u.device)
             kdev = torch.empty(len(sweeps), dtype=torch.float32, device=u.device) if need_grad else None
-            host = torch.empty(len(sweeps), dtype=torch.float32, pin_memory=True) if need_grad else None
+            with torch.cuda.device(u.device):
+                tk = _kmax_channel(len(sweeps)) if need_grad else None
+            host = tk.host if tk else None
             a = arr[i]
             a.desc, a.sweeps_per_step, a.mode = C.pointer(d), sps, 1
             a.M = Mf.data_ptr()
@@ -422,18 +519,15 @@ class _AdiMultiFn(torch.autograd.Function):
             a.steps_workspace, a.steps_workspace_bytes = sws.data_ptr(), sws.numel()
             a.kappa_max = kdev.data_ptr() if kdev is not None else None
             a.kappa_max_host = host.data_ptr() if host is not None else None
-            keep.append((p, Mf, sws, states, kdev, host))
+            keep.append((p, Mf, sws, states, kdev, tk))
             descs.append(d)
             per.append((sps, K, [t.shape for t in (ab, bb, asl, bsl)], M.dtype))
         out = torch.empty_like(u)
         with torch.cuda.device(u.device):
-            ev = None
-            if need_grad:
-                ev = torch.cuda.Event()
-                ev.record()
+            ev = keep[-1][5].event if need_grad else None      # recorded behind the last layer's copy
             L.check(lib.pde_adi_multi_forward(nl, arr, _ptr(u), _ptr(out), C.c_void_p(ev.cuda_event if ev is not None else 0),
                                               _stream()), "pde_adi_multi_forward")
-        ctx.keep, ctx.descs, ctx.per, ctx.ev, ctx.u, ctx.wdev = keep, descs, per, ev, u, wdev
+        ctx.keep, ctx.descs, ctx.per, ctx.u, ctx.wdev = keep, descs, per, u, wdev
         ctx.has_w = weights is not None
         ys = [k[3][-1] for k in keep]                      # the last sweep output of every layer
         return (out, *ys)
@@ -445,14 +539,14 @@ class _AdiMultiFn(torch.autograd.Function):
         u = ctx.u
         B, Cc, N, _ = u.shape
         arr = (L.PdeSmallLayer * nl)()
-        ctx.ev.synchronize()
+        ctx.keep[-1][5].event.synchronize()
         outs, hold = [], []
         gout_c = None if gout is None else gout.to(u.dtype).contiguous()
         for i in range(nl):
-            p, Mf, sws, states, kdev, host = ctx.keep[i]
+            p, Mf, sws, states, kdev, tk = ctx.keep[i]
             sps, K, shapes, Mdt = ctx.per[i]
             d = ctx.descs[i]
-            km = host.tolist()
+            km = tk.host.tolist()
             bits = 0
             for k in range(K):
                 bits |= plan_checkpoints(km[k * sps:(k + 1) * sps])
@@ -495,13 +589,16 @@ def adi_diffuse_multi(u, layers, weights=None):
     ``layers``: list of dicts with keys alpha_base, beta_base, alpha_time_coeff, beta_time_coeff, M, steps and
     optionally smooth3, clamp_max, eps.  ``weights`` (L,): ``out = sum_i weights[i] * y_i`` (cifar10.py:277-280
     without the attention gates); None: ``out`` is not meaningful.  Returns ``(out, [y_1 .. y_L])``."""
-    specs = tuple((tuple(tuple(st) for st in ly["steps"]), bool(ly.get("smooth3", False)), ly.get("clamp_max"),
+    specs = tuple((_as_schedule(ly["steps"]), bool(ly.get("smooth3", False)), ly.get("clamp_max"),
                    float(ly.get("eps", 1e-6))) for ly in layers)
     flat = []
     for ly in layers:
         flat += [ly["alpha_base"], ly["beta_base"], ly["alpha_time_coeff"], ly["beta_time_coeff"], ly["M"]]
     res = _AdiMultiFn.apply(u, weights, specs, *flat)
     return res[0], list(res[1:])
+
+
+_small_ok_cache = {}
 
 
 def adi_small_supported(u, steps, smooth3=False, clamp_max=None, eps=1e-6) -> bool:
@@ -512,8 +609,15 @@ def adi_small_supported(u, steps, smooth3=False, clamp_max=None, eps=1e-6) -> bo
     if B == 0 or Cc > 4 or N > L.PDE_MAX_N or len(steps) * len(steps[0]) > L.PDE_MAX_SWEEPS:
         return False
     io = L.PDE_IO_BF16 if u.dtype == torch.bfloat16 else L.PDE_IO_F32
-    d = _make_desc(B, Cc, N, io, tuple(s for st in steps for s in st), smooth3, clamp_max, eps)
-    return bool(L.load().pde_adi_small_supported(C.byref(d), len(steps[0])))
+    steps = _as_schedule(steps)
+    key = (B, Cc, N, io, steps.flat, bool(smooth3), clamp_max, float(eps), len(steps[0]))
+    ok = _small_ok_cache.get(key)
+    if ok is None:
+        if len(_small_ok_cache) > 256:
+            _small_ok_cache.clear()
+        d = _make_desc(B, Cc, N, io, steps.flat, smooth3, clamp_max, eps)
+        ok = _small_ok_cache[key] = bool(L.load().pde_adi_small_supported(C.byref(d), len(steps[0])))
+    return ok
 
 
 def adi_diffuse_small(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff, M, steps, mode: str, skip_weight=None,
@@ -523,7 +627,7 @@ def adi_diffuse_small(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coef
     time loop in one launch forward and one backward.  Check ``adi_small_supported`` first."""
     if mode not in ("pre", "post"):
         raise ValueError(mode)
-    steps = tuple(tuple(st) for st in steps)
+    steps = _as_schedule(steps)
     return _AdiSmallFn.apply(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff, M, skip_weight, steps, mode,
                              bool(smooth3), clamp_max, float(eps), checkpoints, kmax_sink)
 
@@ -565,12 +669,13 @@ def adi_diffuse(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff, swe
 
     ``checkpoints``: "auto" (default) chooses the backward's checkpoints from the coefficients
     (``plan_checkpoints``); an int is an explicit bit mask (0: rebuild every state from the output).
-    ``kmax_sink``: a list that receives ``(pinned_host_tensor, event)`` with the per-sweep maximum
-    coefficient of this call (valid once the event has completed).
+    ``kmax_sink``: a list that receives an object with ``.host`` (pinned tensor) and ``.event``: the per-sweep
+    maximum coefficient of this call (valid once the event has completed).
     """
     if u.shape[0] == 0:
         return _empty_passthrough(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff)
-    return _AdiFn.apply(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff, tuple(sweeps),
+    return _AdiFn.apply(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff,
+                        sweeps if isinstance(sweeps, tuple) else tuple(sweeps),
                         bool(smooth3), clamp_max, float(eps), checkpoints, kmax_sink)
 
 

@@ -44,7 +44,7 @@ class _AdiBase(nn.Module):
         steps = cache.get(key)
         if steps is None:
             cache.clear()
-            steps = cache[key] = tuple(tuple(st) for st in F_.adi_schedule(self.dt, self.dx, dy, self.num_steps, self._split))
+            steps = cache[key] = F_.Schedule(F_.adi_schedule(self.dt, self.dx, dy, self.num_steps, self._split))
         return steps
 
     def get_alpha_beta_at_time(self, t):
@@ -81,11 +81,11 @@ class _AdiBase(nn.Module):
         old = cache.get(key)
         if old is None:
             cache.clear()
-            host, ev = F_.kappa_max_async(u, *args, flat, **kw)
-            ev.synchronize()
-            old = (host, ev, plan(host.tolist()))
-        elif old[1].query():
-            old = (old[0], old[1], plan(old[0].tolist()))
+            km = F_.kappa_max_async(u, *args, flat, **kw)
+            km.event.synchronize()
+            old = (km, plan(km.host.tolist()))
+        elif old[0].event.query():
+            old = (old[0], plan(old[0].host.tolist()))
         return old, cache, key
 
     def _diffuse(self, u, sweeps):
@@ -99,8 +99,8 @@ class _AdiBase(nn.Module):
         old, cache, key = self._lagged_plan(("plain", len(sweeps), sweeps[0].t), u, args, kw, sweeps,
                                             lambda km: F_.plan_checkpoints(km, F_.CKPT_AMAX / 2))
         sink = []
-        y = F_.adi_diffuse(u, *args, sweeps, checkpoints=old[2], kmax_sink=sink, **kw)
-        cache[key] = (sink[0][0], sink[0][1], old[2]) if sink else old
+        y = F_.adi_diffuse(u, *args, sweeps, checkpoints=old[1], kmax_sink=sink, **kw)
+        cache[key] = (sink[0], old[1]) if sink else old
         return y
 
     def _run(self, u, steps, M=None, mode=None, skip_weight=None):
@@ -108,8 +108,9 @@ class _AdiBase(nn.Module):
         (num_steps > 32 Strang steps) are cut into groups of whole steps, chained through autograd."""
         per = max(1, L.PDE_MAX_SWEEPS // len(steps[0]))
         if len(steps) <= per:
-            return self._diffuse(u, [s for st in steps for s in st]) if M is None else \
-                self._diffuse_mixed(u, steps, M, mode, skip_weight)
+            if M is None:
+                return self._diffuse(u, steps.flat if isinstance(steps, F_.Schedule) else [s for st in steps for s in st])
+            return self._diffuse_mixed(u, steps, M, mode, skip_weight)
         u0 = u
         for i in range(0, len(steps), per):
             grp = steps[i:i + per]
@@ -151,8 +152,8 @@ class _AdiBase(nn.Module):
         old, cache, key = self._lagged_plan(("mixed", len(steps), sps, steps[0][0].t), u, args, kw,
                                             [s for st in steps for s in st], plan)
         sink = []
-        y = run(old[2], sink)
-        cache[key] = (sink[0][0], sink[0][1], old[2]) if sink else old
+        y = run(old[1], sink)
+        cache[key] = (sink[0], old[1]) if sink else old
         return y
 
 
