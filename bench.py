@@ -183,6 +183,44 @@ def config_legs(dev, rank, world, dist_on, quick):
         "SVHN.DiffusionLayer(32,128,num_steps=20) bf16 tensors, 60 sweeps + 20 couplings + skip, batch 512/GPU (BASELINE configs[3])")
     leg("cfg5", c5, (256, 64, 64, 64), torch.float32, 20, k,
         "tiny_imagenet.ImprovedDiffusionLayer(64,64) explicit 5-point step, batch 256/GPU (BASELINE configs[4])")
+
+    # the reference's OWN shapes (C = 3): cifar10.MultiScaleExtractor's three PDE layers on one 128-sample batch,
+    # one launch per pass; host-launch-bound, reported as time per forward+backward
+    with contextlib.redirect_stdout(io.StringIO()):
+        trio = [P.EnhancedDiffusionLayer(32, 3, dt=0.001, num_steps=5, dx=1.0, dy=1.0).to(dev),
+                P.EnhancedDiffusionLayer(32, 3, dt=0.002, num_steps=8, dx=2.0, dy=2.0).to(dev),
+                P.EnhancedDiffusionLayer(32, 3, dt=0.005, num_steps=4, dx=1.5, dy=1.5).to(dev)]
+    g = torch.Generator().manual_seed(99 + rank)
+    x = torch.randn(128, 3, 32, 32, generator=g).to(dev).requires_grad_(True)
+    gx = torch.randn(128, 3, 32, 32, generator=g).to(dev)
+    w = torch.full((3,), 1.0 / 3, device=dev, requires_grad=True)
+
+    def trio_step(fused):
+        for ly in trio:
+            for p_ in ly.parameters():
+                p_.grad = None
+        x.grad = None
+        if fused:
+            out, _ = P.diffuse_shared_input(trio, x, w)
+        else:
+            out = sum(wi * ly(x) for wi, ly in zip(w, trio))
+        out.backward(gx)
+    res = {}
+    for fused in (True, False):
+        for _ in range(5):
+            trio_step(fused)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3 * k):
+            trio_step(fused)
+        torch.cuda.synchronize()
+        res[fused] = (time.perf_counter() - t0) / (3 * k) * 1e3
+    if rank == 0:
+        legs["cifar10_trio_c3"] = {"workload": "the three EnhancedDiffusionLayers of cifar10.MultiScaleExtractor (C=3, 5/8/4 steps) on one "
+                                               "(128,3,32,32) batch + weighted sum, forward+backward (reference shapes, cifar10.py:251-280)",
+                                   "ms_per_step": res[True], "ms_per_step_one_call_per_layer": res[False],
+                                   "value": 128 / res[True] / 1e3, "unit": "Msamples/s",
+                                   "note": "one launch per pass for all three layers (pde_adi_multi_*); bound by the host's launch path"}
     return legs
 
 
