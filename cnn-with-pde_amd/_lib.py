@@ -39,10 +39,10 @@ class PdeSmallLayer(C.Structure):
     _fields_ = [("desc", C.POINTER(PdeAdiDesc)), ("sweeps_per_step", C.c_int32), ("mode", C.c_int32),
                 ("M", C.c_void_p), ("skip_weight", C.c_void_p),
                 ("alpha_base", C.c_void_p), ("beta_base", C.c_void_p), ("alpha_slope", C.c_void_p), ("beta_slope", C.c_void_p),
-                ("weight", C.c_float), ("weight_ptr", C.c_void_p), ("states", C.c_void_p),
+                ("weight", C.c_float), ("weight_ptr", C.c_void_p), ("states", C.c_void_p), ("plane_sums", C.c_void_p),
                 ("steps_workspace", C.c_void_p), ("steps_workspace_bytes", C.c_size_t),
                 ("kappa_max", C.c_void_p), ("kappa_max_host", C.c_void_p),
-                ("gys", C.c_void_p), ("ckpt_mask", C.POINTER(C.c_uint64)),
+                ("gys", C.c_void_p), ("g_plane_sums", C.c_void_p), ("ckpt_mask", C.POINTER(C.c_uint64)),
                 ("g_alpha_base", C.c_void_p), ("g_beta_base", C.c_void_p), ("g_alpha_slope", C.c_void_p),
                 ("g_beta_slope", C.c_void_p), ("gM", C.c_void_p), ("g_skip_weight", C.c_void_p), ("g_weight", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
@@ -82,6 +82,10 @@ SIGNATURES = {
                                          _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _vp, _sz, _vp]),
     "pde_adi_multi_forward": (C.c_int, [_i32, C.POINTER(PdeSmallLayer), _vp, _vp, _vp, _vp]),
     "pde_adi_multi_backward": (C.c_int, [_i32, C.POINTER(PdeSmallLayer), _vp, _vp, _vp, _vp]),
+    "pde_gate_combine_forward": (C.c_int, [_i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _fp,
+                                           _vp, _vp]),
+    "pde_gate_combine_backward": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                            _fp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _vp]),
     "pde_channel_mix_forward": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _fp, _vp, _vp]),
     "pde_channel_mix_backward_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "pde_channel_mix_backward": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _fp, _vp, _fp, _vp, _sz, _vp]),

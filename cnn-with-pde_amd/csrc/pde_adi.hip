@@ -1025,6 +1025,7 @@ int pde_adi_multi_forward(int32_t num_layers, const PdeSmallLayer* layers, const
         if (rc != PDE_OK) return rc;
         small_fill(sa.layer[i], y.desc, y.sweeps_per_step, y.mode, y.steps_workspace, y.M, y.skip_weight, y.weight, y.weight_ptr);
         sa.layer[i].states = y.states;
+        sa.layer[i].psum = y.plane_sums;
     }
     if (kappa_event && hipEventRecord(static_cast<hipEvent_t>(kappa_event), st) != hipSuccess) return PDE_E_LAUNCH;
     return dispatch_small(true, d0, small_split(d0, layers[0].sweeps_per_step), sa, small_lds_fwd(d0->C), st);
@@ -1051,7 +1052,7 @@ int pde_adi_multi_backward(int32_t num_layers, const PdeSmallLayer* layers, cons
     bool any_ck = false;
     for (int i = 0; i < num_layers; ++i) {
         const PdeSmallLayer& y = layers[i];
-        if (!y.states || !y.gM || !y.workspace || (!gy && !y.gys) || !y.g_alpha_base || !y.g_beta_base || !y.g_alpha_slope ||
+        if (!y.states || !y.gM || !y.workspace || (!gy && !y.gys && !y.g_plane_sums) || !y.g_alpha_base || !y.g_beta_base || !y.g_alpha_slope ||
             !y.g_beta_slope || (y.skip_weight && !y.g_skip_weight))
             return PDE_E_BADARG;
         PdeAdiDesc ds;
@@ -1081,6 +1082,7 @@ int pde_adi_multi_backward(int32_t num_layers, const PdeSmallLayer* layers, cons
     for (int i = 0; i < num_layers; ++i) {
         sa.layer[i].states = const_cast<void*>(layers[i].states);
         sa.layer[i].gys = layers[i].gys;
+        sa.layer[i].roff = layers[i].g_plane_sums;
     }
     rc = dispatch_small(false, d0, split, sa, small_lds_bwd(d0->C), st);
     if (rc != PDE_OK) return rc;

@@ -38,6 +38,8 @@ struct SmallLayer {
     void* states;           // [K][B][C][N][N] of the tensor type: sweep output of every step (fwd: null = do not keep)
     float* ckpt;            // [K][nck][B][C][N][N] fp32: states inside a step (null: none)
     const void* gys;        // bwd: dL/dy_i on top of w_i dL/dout (null: none)
+    const float* roff;      // bwd: [B][C] dL/d(plane sum of y_i), added to every element of the plane's gradient (null: none)
+    float* psum;            // fwd: [B][C] sum of y_i over the plane (the average pool of cifar10.py:239; null: not wanted)
     float* part;            // bwd: [grid][C][4][kImage]
     float* gm_part;         // bwd: [grid][C][kGmStride]
     unsigned long long ck[2];   // bit i: the state after sweep i of EVERY step is checkpointed
@@ -136,6 +138,7 @@ __global__ __launch_bounds__(64 * kSmallMaxC) void adi_small_fwd_kernel(SmallArg
         const float* skp = Lp->skip_w;
         IO* st = static_cast<IO*>(Lp->states);
         float* ckpt = Lp->ckpt;
+        float* psum = Lp->psum;
         const unsigned long long ck[2] = {Lp->ck[0], Lp->ck[1]};
         const int nck = Lp->nck, K = Lp->K, mode = Lp->mode, S = K * SPS;
         const float* wpp = Lp->wp;
@@ -208,6 +211,14 @@ __global__ __launch_bounds__(64 * kSmallMaxC) void adi_small_fwd_kernel(SmallArg
                 if (skp != nullptr) {                                     // SVHN.py:74  sigmoid(w) u0 + (1 - sigmoid(w)) u
 #pragma unroll
                     for (int q = 0; q < M; ++q) v[q] = sk * u0[q] + (1.0f - sk) * v[q];
+                }
+                if (psum != nullptr) {                                    // spatial sum of y_i: SpatialAttention's pool for free
+                    float t = 0.f;
+#pragma unroll
+                    for (int q = 0; q < M; ++q) t += v[q];
+                    t = (l < N) ? t : 0.f;
+                    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+                    if (lane == 0) psum[(size_t)b * nC + c] = t;
                 }
                 if (a.L > 1) {                                            // out = sum_i w_i y_i: my own earlier store, re-read
                     if (li > 0) {
@@ -302,6 +313,7 @@ __global__ __launch_bounds__(64 * kSmallMaxC) void adi_small_bwd_kernel(SmallArg
         const float* skp = Lp->skip_w;
         const IO* st = static_cast<const IO*>(Lp->states);
         const IO* gys = static_cast<const IO*>(Lp->gys);
+        const float* roff = Lp->roff;
         const float* ckpt = Lp->ckpt;
         const unsigned long long ck[2] = {Lp->ck[0], Lp->ck[1]};
         const int nck = Lp->nck, K = Lp->K, mode = Lp->mode, S = K * SPS, smooth = Lp->smooth3;
@@ -378,6 +390,11 @@ __global__ __launch_bounds__(64 * kSmallMaxC) void adi_small_bwd_kernel(SmallArg
                 small_load<N, 0, IO>(gys, b, nC, c, lane, l, hf, T, gi);
 #pragma unroll
                 for (int k = 0; k < M; ++k) r[k] += gi[k];
+            }
+            if (roff != nullptr) {                                        // ... and at its spatial sum (the average pool)
+                const float ro = live * roff[(size_t)b * nC + c];
+#pragma unroll
+                for (int k = 0; k < M; ++k) r[k] += ro;
             }
 #pragma unroll
             for (int k = 0; k < M; ++k) { gsk[k] = sk * r[k]; r[k] = (1.0f - sk) * r[k]; }     // sk = 0 without a skip blend

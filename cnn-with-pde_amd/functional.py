@@ -14,7 +14,7 @@ import torch
 
 from . import _lib as L
 
-__all__ = ["Sweep", "adi_schedule", "adi_diffuse", "adi_diffuse_mixed", "adi_diffuse_small", "adi_small_supported", "adi_diffuse_multi", "plan_checkpoints", "kappa_max_async", "channel_mix", "skip_blend", "explicit5_step", "jacobi_diffuse",
+__all__ = ["Sweep", "adi_schedule", "adi_diffuse", "adi_diffuse_mixed", "adi_diffuse_small", "adi_small_supported", "adi_diffuse_multi", "gate_combine", "plan_checkpoints", "kappa_max_async", "channel_mix", "skip_blend", "explicit5_step", "jacobi_diffuse",
            "timing_enable", "timing_read", "Schedule"]
 
 
@@ -483,7 +483,7 @@ class _AdiMultiFn(torch.autograd.Function):
     Returns (sum_i w_i y_i, y_1, ..., y_L); the y_i are the last sweep outputs the kernel keeps anyway."""
 
     @staticmethod
-    def forward(ctx, u, weights, specs, *flat):
+    def forward(ctx, u, weights, specs, want_sums, *flat):
         lib = L.load()
         nl = len(specs)
         _require_cuda(u, weights, *flat)
@@ -495,7 +495,7 @@ class _AdiMultiFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         wdev = None if weights is None else weights.detach().to(torch.float32).contiguous()   # read by the kernels on the device
         arr = (L.PdeSmallLayer * nl)()
-        keep, descs, per = [], [], []
+        keep, descs, per, sums = [], [], [], []
         for i, (steps, smooth3, clamp_max, eps) in enumerate(specs):
             ab, bb, asl, bsl, M = flat[5 * i:5 * i + 5]
             sps, K = len(steps[0]), len(steps)
@@ -519,6 +519,9 @@ class _AdiMultiFn(torch.autograd.Function):
             a.steps_workspace, a.steps_workspace_bytes = sws.data_ptr(), sws.numel()
             a.kappa_max = kdev.data_ptr() if kdev is not None else None
             a.kappa_max_host = host.data_ptr() if host is not None else None
+            psum = torch.empty((B, Cc), dtype=torch.float32, device=u.device) if want_sums else None
+            a.plane_sums = psum.data_ptr() if psum is not None else None
+            sums.append(psum)
             keep.append((p, Mf, sws, states, kdev, tk))
             descs.append(d)
             per.append((sps, K, [t.shape for t in (ab, bb, asl, bsl)], M.dtype))
@@ -529,13 +532,15 @@ class _AdiMultiFn(torch.autograd.Function):
                                               _stream()), "pde_adi_multi_forward")
         ctx.keep, ctx.descs, ctx.per, ctx.u, ctx.wdev = keep, descs, per, u, wdev
         ctx.has_w = weights is not None
+        ctx.want_sums = want_sums
         ys = [k[3][-1] for k in keep]                      # the last sweep output of every layer
-        return (out, *ys)
+        return (out, *ys, *sums) if want_sums else (out, *ys)
 
     @staticmethod
-    def backward(ctx, gout, *gys):
+    def backward(ctx, gout, *gall):
         lib = L.load()
         nl = len(ctx.per)
+        gys, gsums = gall[:nl], (gall[nl:] if ctx.want_sums else (None,) * nl)
         u = ctx.u
         B, Cc, N, _ = u.shape
         arr = (L.PdeSmallLayer * nl)()
@@ -556,6 +561,7 @@ class _AdiMultiFn(torch.autograd.Function):
             gM = torch.empty_like(Mf)
             gw = torch.empty(1, dtype=torch.float32, device=u.device)
             gyi = None if gys[i] is None else gys[i].to(u.dtype).contiguous()
+            gsi = None if gsums[i] is None else gsums[i].to(torch.float32).contiguous()
             a = arr[i]
             a.desc, a.sweeps_per_step, a.mode = C.pointer(d), sps, 1
             a.M = Mf.data_ptr()
@@ -565,13 +571,14 @@ class _AdiMultiFn(torch.autograd.Function):
             a.states = states.data_ptr()
             a.steps_workspace, a.steps_workspace_bytes = sws.data_ptr(), sws.numel()
             a.gys = gyi.data_ptr() if gyi is not None else None
+            a.g_plane_sums = gsi.data_ptr() if gsi is not None else None
             a.ckpt_mask = mask
             a.g_alpha_base, a.g_beta_base, a.g_alpha_slope, a.g_beta_slope = (t.data_ptr() for t in gp)
             a.gM, a.g_weight = gM.data_ptr(), gw.data_ptr()
             a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
-            hold.append((mask, ws, gyi))
+            hold.append((mask, ws, gyi, gsi))
             outs.append((gp, gM, gw, shapes, Mdt))
-        if gout_c is None and all(h[2] is None for h in hold):
+        if gout_c is None and all(h[2] is None and h[3] is None for h in hold):
             raise L.PdeError("adi_diffuse_multi: no incoming gradient")
         gu = torch.empty_like(u)
         with torch.cuda.device(u.device):
@@ -580,21 +587,26 @@ class _AdiMultiFn(torch.autograd.Function):
         for gp, gM, gw, shapes, Mdt in outs:
             flat += [g.reshape(s) for g, s in zip(gp, shapes)] + [gM.to(Mdt)]
         gweights = torch.cat([o[2] for o in outs]) if ctx.has_w else None
-        return (gu, gweights, None, *flat)
+        return (gu, gweights, None, None, *flat)
 
 
-def adi_diffuse_multi(u, layers, weights=None):
+def adi_diffuse_multi(u, layers, weights=None, plane_sums=False):
     """Run several mixing-first layers on the same ``u`` in one launch per pass.
 
     ``layers``: list of dicts with keys alpha_base, beta_base, alpha_time_coeff, beta_time_coeff, M, steps and
     optionally smooth3, clamp_max, eps.  ``weights`` (L,): ``out = sum_i weights[i] * y_i`` (cifar10.py:277-280
-    without the attention gates); None: ``out`` is not meaningful.  Returns ``(out, [y_1 .. y_L])``."""
+    without the attention gates); None: ``out`` is not meaningful.  Returns ``(out, [y_1 .. y_L])``, and with
+    ``plane_sums`` also ``[s_1 .. s_L]``, ``s_i[b,c] = sum_hw y_i`` — the adaptive average pool of
+    cifar10.py:239 times H*W, a by-product of the kernel (differentiable like the ``y_i``)."""
     specs = tuple((_as_schedule(ly["steps"]), bool(ly.get("smooth3", False)), ly.get("clamp_max"),
                    float(ly.get("eps", 1e-6))) for ly in layers)
     flat = []
     for ly in layers:
         flat += [ly["alpha_base"], ly["beta_base"], ly["alpha_time_coeff"], ly["beta_time_coeff"], ly["M"]]
-    res = _AdiMultiFn.apply(u, weights, specs, *flat)
+    res = _AdiMultiFn.apply(u, weights, specs, bool(plane_sums), *flat)
+    nl = len(layers)
+    if plane_sums:
+        return res[0], list(res[1:1 + nl]), list(res[1 + nl:])
     return res[0], list(res[1:])
 
 
@@ -720,6 +732,63 @@ def channel_mix(u, M):
     if u.shape[0] == 0:
         return _empty_passthrough(u, M)
     return _MixFn.apply(u, M)
+
+
+# --------------------------------------------------------------------------- attention gates + weighted combination
+class _GateCombineFn(torch.autograd.Function):
+    """combined = sum_i w_i gate_i[b,c] y_i — cifar10.py:242 (x * attention_weights) and :277-280 in one pass; the
+    backward in one pass too (scaled gradients of the y_i and the per-plane dots the gate/weight gradients need)."""
+
+    @staticmethod
+    def forward(ctx, weights, nl, *rest):
+        lib = L.load()
+        ys, gates = rest[:nl], rest[nl:]
+        _require_cuda(weights, *rest)
+        y0 = ys[0]
+        dt = y0.dtype if y0.dtype in (torch.float32, torch.bfloat16) else torch.float32
+        ys_c = [y.to(dt).contiguous() for y in ys]
+        B, Cc = y0.shape[:2]
+        HW = y0[0, 0].numel()
+        g_c = [g.detach().to(torch.float32).reshape(B, Cc).contiguous() for g in gates]
+        w_c = weights.detach().to(torch.float32).contiguous()
+        out = torch.empty_like(ys_c[0])
+        yp = (C.c_void_p * nl)(*[y.data_ptr() for y in ys_c])
+        gp = (C.c_void_p * nl)(*[g.data_ptr() for g in g_c])
+        with torch.cuda.device(y0.device):
+            L.check(lib.pde_gate_combine_forward(nl, B, Cc, HW, _io_dtype(ys_c[0]), yp, gp, _ptr(w_c), _ptr(out), _stream()),
+                    "pde_gate_combine_forward")
+        ctx.save_for_backward(w_c, *ys_c, *g_c)
+        ctx.nl = nl
+        ctx.meta = (weights.dtype, [y.dtype for y in ys], [(g.dtype, g.shape) for g in gates])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = L.load()
+        nl = ctx.nl
+        w_c, *rest = ctx.saved_tensors
+        ys_c, g_c = rest[:nl], rest[nl:]
+        B, Cc = ys_c[0].shape[:2]
+        HW = ys_c[0][0, 0].numel()
+        g = g.to(ys_c[0].dtype).contiguous()
+        gys = [torch.empty_like(y) for y in ys_c]
+        dots = [torch.empty((B, Cc), dtype=torch.float32, device=g.device) for _ in range(nl)]
+        yp = (C.c_void_p * nl)(*[y.data_ptr() for y in ys_c])
+        gp = (C.c_void_p * nl)(*[t.data_ptr() for t in g_c])
+        gyp = (C.c_void_p * nl)(*[t.data_ptr() for t in gys])
+        dp = (C.c_void_p * nl)(*[t.data_ptr() for t in dots])
+        with torch.cuda.device(g.device):
+            L.check(lib.pde_gate_combine_backward(nl, B, Cc, HW, _io_dtype(g), _ptr(g), yp, gp, _ptr(w_c), gyp, dp, _stream()),
+                    "pde_gate_combine_backward")
+        wdt, ydts, gmeta = ctx.meta
+        gw = torch.stack([(g_c[i] * dots[i]).sum() for i in range(nl)]).to(wdt)
+        ggates = [(w_c[i] * dots[i]).to(gmeta[i][0]).reshape(gmeta[i][1]) for i in range(nl)]
+        return (gw, None, *[t.to(d) for t, d in zip(gys, ydts)], *ggates)
+
+
+def gate_combine(ys, gates, weights):
+    """``sum_i weights[i] * gates[i][:, :, None, None] * ys[i]`` in one pass over the tensors (cifar10.py:242,277-280)."""
+    return _GateCombineFn.apply(weights, len(ys), *ys, *gates)
 
 
 # --------------------------------------------------------------------------- explicit layers

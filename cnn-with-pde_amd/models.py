@@ -31,10 +31,10 @@ __all__ = ["MnistPDEClassifier", "FashionPDEClassifier", "SvhnPDEClassifier", "S
            "diffuse_shared_input"]
 
 
-def diffuse_shared_input(layers, x, weights=None):
+def diffuse_shared_input(layers, x, weights=None, plane_sums=False):
     """Run mixing-first PDE layers (``EnhancedDiffusionLayer`` / ``LearnableDiffusionLayer``) that share the input
     ``x`` in ONE launch per pass when the library supports the shapes (C <= 4), else one after the other.
-    Returns ``(sum_i weights[i] * y_i or None, [y_1 .. y_L])``."""
+    Returns ``(sum_i weights[i] * y_i or None, [y_1 .. y_L])``; with ``plane_sums`` also ``[sum_hw y_i]`` (B,C)."""
     steps = [ly._schedule() for ly in layers]
     same_split = len({len(st[0]) for st in steps}) == 1
     fused = (same_split and len(layers) <= 4 and x.is_cuda and all(getattr(ly, "channel_mixing_enabled", True) for ly in layers)
@@ -44,12 +44,13 @@ def diffuse_shared_input(layers, x, weights=None):
     if not fused:
         ys = [ly(x) for ly in layers]
         out = None if weights is None else sum(w * y for w, y in zip(weights, ys))
-        return out, ys
+        return (out, ys, [y.sum(dim=(2, 3)) for y in ys]) if plane_sums else (out, ys)
     descr = [dict(alpha_base=ly.alpha_base, beta_base=ly.beta_base, alpha_time_coeff=ly.alpha_time_coeff,
                   beta_time_coeff=ly.beta_time_coeff, M=ly.channel_mixing, steps=st, smooth3=ly._smooth3,
                   clamp_max=ly._clamp_max, eps=ly.stability_eps) for ly, st in zip(layers, steps)]
-    out, ys = F_.adi_diffuse_multi(x, descr, weights)
-    return (out if weights is not None else None), ys
+    res = F_.adi_diffuse_multi(x, descr, weights, plane_sums)
+    out = res[0] if weights is not None else None
+    return (out, res[1], res[2]) if plane_sums else (out, res[1])
 
 
 class MnistPDEClassifier(nn.Module):
@@ -118,6 +119,10 @@ class SpatialAttention(nn.Module):
         self.attention_fc = nn.Sequential(nn.Linear(channels, channels * 2), nn.ReLU(),
                                           nn.Linear(channels * 2, channels), nn.Sigmoid())
 
+    def gate(self, plane_sums, hw):
+        """The gate from the spatial SUM of x (B,C): mean(x + pos_embed) = sum(x)/HW + mean(pos_embed)."""
+        return self.attention_fc(plane_sums / hw + self.pos_embed.mean(dim=(2, 3)))
+
     def forward(self, x):
         B, C = x.shape[:2]
         pooled = F.adaptive_avg_pool2d(x + self.pos_embed, (1, 1)).view(B, C)
@@ -140,11 +145,29 @@ class MultiScaleExtractor(nn.Module):
         self.combine_weights = nn.Parameter(torch.ones(3) / 3)
         print("Multi-scale α/β learning: 3 PDE layers with different temporal/spatial scales")
 
+    #: False: return (combined, None, None, None) and never materialise the three gated feature maps (the reference's
+    #: own model, cifar10.py:343, drops them)
+    return_features = True
+    #: False: attention and combination as plain torch ops (x + pos, pool, multiply, weighted adds: ~14 passes)
+    fused_epilogue = True
+
     def forward(self, x):
-        _, (y1, y2, y3) = diffuse_shared_input([self.pde1, self.pde2, self.pde3], x)
-        f1, f2, f3 = self.attention1(y1), self.attention2(y2), self.attention3(y3)
+        att = (self.attention1, self.attention2, self.attention3)
         w = F.softmax(self.combine_weights, dim=0)
-        return w[0] * f1 + w[1] * f2 + w[2] * f3, f1, f2, f3
+        if not (self.fused_epilogue and x.is_cuda):
+            _, ys = diffuse_shared_input([self.pde1, self.pde2, self.pde3], x)
+            f1, f2, f3 = (a(y) for a, y in zip(att, ys))
+            return w[0] * f1 + w[1] * f2 + w[2] * f3, f1, f2, f3
+        # the average pool comes out of the PDE kernel, the (B,C) MLPs stay in torch, gate multiply and weighted sum
+        # are one pass (functional.gate_combine): SURVEY §8f-3
+        _, ys, sums = diffuse_shared_input([self.pde1, self.pde2, self.pde3], x, plane_sums=True)
+        hw = x.shape[2] * x.shape[3]
+        gates = [a.gate(s, hw) for a, s in zip(att, sums)]
+        combined = F_.gate_combine(ys, gates, w)
+        if not self.return_features:
+            return combined, None, None, None
+        B, C = x.shape[:2]
+        return (combined, *[y * g.view(B, C, 1, 1) for y, g in zip(ys, gates)])
 
 
 class EnhancedFC(nn.Module):
@@ -173,6 +196,7 @@ class CIFAR10PDENoConv(nn.Module):
     def __init__(self, dropout_rate=0.3):
         super().__init__()
         self.feature_extractor = MultiScaleExtractor(input_size=32, channels=3)
+        self.feature_extractor.return_features = False       # forward() below uses `combined` only (cifar10.py:343)
         self.adaptive_pool = nn.AdaptiveAvgPool2d((4, 4))
         self.max_pool = nn.AdaptiveMaxPool2d((4, 4))
         self.classifier = EnhancedFC(96, [512, 256, 128, 64], 10, dropout_rate)

@@ -218,10 +218,13 @@ typedef struct PdeSmallLayer {
     float weight;                    /* weight_i ...                                                           */
     const float* weight_ptr;         /* ... or, when not NULL, a device scalar holding it (no host round trip)  */
     void* states;                    /* K_i tensors (forward: NULL = inference)                                */
+    float* plane_sums;               /* NULL | (B,C): forward writes sum over the plane of y_i (the adaptive average
+                                        pool of cifar10.py:239 times H*W, at no extra pass)                      */
     void* steps_workspace; size_t steps_workspace_bytes;     /* pde_adi_steps_workspace_bytes(desc, sps)      */
     float* kappa_max; float* kappa_max_host;                 /* optional, as in pde_adi_forward               */
     /* backward only */
     const void* gys;                 /* NULL | dL/dy_i                                                         */
+    const float* g_plane_sums;       /* NULL | (B,C) dL/d(plane_sums_i): added to every element of the plane    */
     const uint64_t* ckpt_mask;       /* relative to a step                                                     */
     float* g_alpha_base; float* g_beta_base; float* g_alpha_slope; float* g_beta_slope;
     float* gM; float* g_skip_weight; float* g_weight;        /* g_weight optional                              */
@@ -264,6 +267,22 @@ size_t pde_skip_blend_backward_workspace_bytes(int64_t n);
 int pde_skip_blend_backward(int64_t n, int32_t io_dtype, const void* g, const void* u0, const void* u,
                             const float* skip_weight, void* g_u0, void* g_u, float* g_skip_weight,
                             void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- epilogue behind the shared-input layers -------------------------------------------
+ * cifar10.py:270-280: features_i = y_i * gate_i[b,c] (SpatialAttention :232-244), combined = sum_i w_i features_i.
+ * The gates are a small MLP of the average pool of y_i + pos_embed: the pool comes out of pde_adi_multi_forward
+ * (PdeSmallLayer.plane_sums), the (B,C) MLP stays with the caller; these two calls are the passes over the full
+ * tensors that remain.  ys: L <= 4 tensors (B,C,HW) of io_dtype; gates: L arrays (B,C) fp32; weights: (L) fp32 on
+ * the device; HW a multiple of 4.
+ *   forward : out[b,c,p]  = sum_i weights[i] gates[i][b,c] ys[i][b,c,p]
+ *   backward: gys[i][b,c,p] = weights[i] gates[i][b,c] g[b,c,p];  dots[i][b,c] = sum_p g[b,c,p] ys[i][b,c,p]
+ *             (dL/dgate_i = weights[i] dots[i], dL/dweights[i] = sum_bc gates[i] dots[i]). */
+int pde_gate_combine_forward(int32_t L, int32_t B, int32_t C, int32_t HW, int32_t io_dtype,
+                             const void* const* ys, const float* const* gates, const float* weights,
+                             void* out, void* stream);
+int pde_gate_combine_backward(int32_t L, int32_t B, int32_t C, int32_t HW, int32_t io_dtype, const void* g,
+                              const void* const* ys, const float* const* gates, const float* weights,
+                              void* const* gys, float* const* dots, void* stream);
 
 /* ---- K2: explicit 5-point layers --------------------------- */
 

@@ -23,15 +23,19 @@ def quiet(fn, *a, **k):
 
 
 @pytest.mark.parametrize("name", G.names(directory=G.MODEL_DIR))
-@pytest.mark.parametrize("fused", [True, False])
-def test_model_matches_reference_vectors(name, fused):
-    """tests/golden_models: made by tools/make_golden.py from the reference's own module (eval mode)."""
+@pytest.mark.parametrize("fused,epilogue", [(True, True), (True, False), (False, True), (False, False)])
+def test_model_matches_reference_vectors(name, fused, epilogue):
+    """tests/golden_models: made by tools/make_golden.py from the reference's own module (eval mode).  fused: the
+    three PDE layers in one launch per pass; epilogue: average pool out of the PDE kernel + gate/combine in one pass."""
     import cnn_with_pde_amd as P
     g = G.Golden(name, G.MODEL_DIR)
     model = quiet(P.REFERENCE_CLASSES[(g.script, g.cls)], **g.ctor)
     missing = model.load_state_dict({k: v.float() for k, v in g.params.items()}, strict=False)
     assert not missing.unexpected_keys and not missing.missing_keys, missing      # the reference's names, all of them
     model = model.cuda().eval()
+    for m in model.modules():
+        if hasattr(m, "fused_epilogue"):
+            m.fused_epilogue = epilogue
     if not fused:
         for m in model.modules():
             if hasattr(m, "small_channel_kernels"):
@@ -52,6 +56,63 @@ def test_model_matches_reference_vectors(name, fused):
     # reductions on both sides, summation order not pinned): held to 1e-4, everything else to 1e-5
     bad = {k: v for k, v in errs.items() if not v <= (1e-4 if k == "g_combine_weights" else TOL)}
     assert not bad, (bad, errs)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gate_combine_vs_torch(dtype):
+    """combined = sum_i w_i gate_i y_i and all its gradients against the torch expression (fp64)."""
+    import cnn_with_pde_amd as P
+    g = torch.Generator().manual_seed(3)
+    L_, B, C, H = 3, 5, 3, 32
+    ys = [torch.randn(B, C, H, H, generator=g).to(dtype) for _ in range(L_)]
+    gates = [torch.rand(B, C, generator=g) for _ in range(L_)]
+    w = torch.softmax(torch.randn(L_, generator=g), 0)
+    go = torch.randn(B, C, H, H, generator=g).to(dtype)
+    yr = [y.double().requires_grad_(True) for y in ys]
+    gr = [t.double().requires_grad_(True) for t in gates]
+    wr = w.double().requires_grad_(True)
+    ref = sum(wr[i] * gr[i].view(B, C, 1, 1) * yr[i] for i in range(L_))
+    ref.backward(go.double())
+    yd = [y.cuda().requires_grad_(True) for y in ys]
+    gd = [t.cuda().requires_grad_(True) for t in gates]
+    wd = w.cuda().requires_grad_(True)
+    out = P.gate_combine(yd, gd, wd)
+    assert out.dtype == dtype
+    out.backward(go.cuda())
+    tol = 1e-6 if dtype == torch.float32 else 8e-3
+    assert G.rel_err(out.detach().float().cpu(), ref.detach()) <= tol
+    for i in range(L_):
+        assert G.rel_err(yd[i].grad.float().cpu(), yr[i].grad) <= tol
+        assert G.rel_err(gd[i].grad.cpu(), gr[i].grad) <= (1e-5 if dtype == torch.float32 else 1e-5)
+    assert G.rel_err(wd.grad.cpu(), wr.grad) <= 1e-5
+
+
+def test_plane_sums_by_product_and_their_gradient():
+    """sum_hw y_i out of the PDE kernel, and a gradient arriving at it (SpatialAttention's pool path)."""
+    import cnn_with_pde_amd as P
+    g = torch.Generator().manual_seed(8)
+    N, C, B = 32, 3, 4
+    layers = [quiet(P.EnhancedDiffusionLayer, N, C, dt=0.02, num_steps=3).cuda(),
+              quiet(P.EnhancedDiffusionLayer, N, C, dt=0.05, num_steps=2, dx=1.5, dy=1.5).cuda()]
+    u = torch.randn(B, C, N, N, generator=g).cuda()
+    a = torch.randn(2, B, C, generator=g).cuda()
+    u1 = u.clone().requires_grad_(True)
+    _, ys, sums = P.diffuse_shared_input(layers, u1, plane_sums=True)
+    for y, s in zip(ys, sums):
+        assert G.rel_err(s.detach().cpu(), y.detach().sum(dim=(2, 3)).cpu()) <= 1e-5
+    (sums[0] * a[0]).sum().add((sums[1] * a[1]).sum()).add(ys[1].square().sum()).backward()
+    got = {n: p.grad.clone() for i, ly in enumerate(layers) for n, p in ((f"{i}.{k}", v) for k, v in ly.named_parameters())}
+    gu1 = u1.grad.clone()
+    for ly in layers:
+        for p in ly.parameters():
+            p.grad = None
+    u2 = u.clone().requires_grad_(True)
+    y0, y1 = layers[0](u2), layers[1](u2)                 # the same through separate calls and torch sums
+    ((y0.sum(dim=(2, 3)) * a[0]).sum() + (y1.sum(dim=(2, 3)) * a[1]).sum() + y1.square().sum()).backward()
+    assert G.rel_err(gu1.cpu(), u2.grad.cpu()) <= 5e-6
+    for i, ly in enumerate(layers):
+        for k, v in ly.named_parameters():
+            assert G.rel_err(got[f"{i}.{k}"].cpu(), v.grad.cpu()) <= 1e-5, (i, k)
 
 
 @pytest.mark.parametrize("kind", ["cifar10x3", "cifar2x2"])
@@ -116,7 +177,7 @@ def _fit(model, x, target, steps, lr, amp=False, params=None):
         torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
         scaler.step(opt)
         scaler.update()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     return losses
 
 
