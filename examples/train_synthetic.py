@@ -6,8 +6,15 @@ the optimiser recipe of mnist_test.py:282-306: AdamW, cosine schedule, label smo
 with the diffusion layer taken from this package and data parallelism over RCCL:
 
     python examples/train_synthetic.py --variant mnist --steps 200
+    python examples/train_synthetic.py --variant cifar10_noconv --amp          # cifar10.py:318-361 under fp16 autocast
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
-        examples/train_synthetic.py --variant cifar10 --steps 200
+        examples/train_synthetic.py --variant svhn_model --steps 200
+
+Variants: ``mnist`` / ``cifar10`` are small stand-ins; ``mnist_model``, ``fashion_model``, ``svhn_model``,
+``cifar10_noconv``, ``tiny_model`` and ``emotion_model`` are the counterparts of the reference's own models
+(cnn_with_pde_amd.models: mnist_test.py:223-237, fashion_mnist.py:200-224, SVHN.py:234-270, cifar10.py:318-361,
+tiny_imagenet.py:237-305, emotion_recognition.py:170-195).  ``--amp`` runs the step under fp16 autocast with a
+GradScaler, as cifar10.py:440,458-467 does.
 
 There is no dataset on the box: every rank draws its shard of a fixed synthetic classification task
 (one smooth random template per class plus noise), so the loss has something to learn and the run is
@@ -62,15 +69,29 @@ class Cifar10Like(nn.Module):
         return self.head(F.adaptive_avg_pool2d(x, 4).flatten(1))
 
 
+#: variant -> (model factory, (channels, size), classes)
+VARIANTS = {
+    "mnist": (lambda: MnistLike(), (1, 28), 10),
+    "cifar10": (lambda: Cifar10Like(), (3, 32), 10),
+    "mnist_model": (lambda: quiet(P.MnistPDEClassifier), (1, 28), 10),
+    "fashion_model": (lambda: quiet(P.FashionPDEClassifier), (1, 28), 10),
+    "svhn_model": (lambda: quiet(P.SvhnPDEClassifier), (3, 32), 10),
+    "cifar10_noconv": (lambda: quiet(P.CIFAR10PDENoConv), (3, 32), 10),
+    "tiny_model": (lambda: quiet(P.TinyImageNetClassifier, num_classes=20), (3, 64), 20),
+    "emotion_model": (lambda: quiet(P.EmotionDiffusionClassifier), (1, 48), 7),
+}
+
+
 def synthetic_task(variant, classes, gen):
-    c, n = (1, 28) if variant == "mnist" else (3, 32)
-    coarse = torch.randn(classes, c, 7 if n == 28 else 8, 7 if n == 28 else 8, generator=gen)
+    c, n = VARIANTS[variant][1]
+    coarse = torch.randn(classes, c, n // 4, n // 4, generator=gen)
     return F.interpolate(coarse, size=(n, n), mode="bilinear", align_corners=False)        # smooth class templates
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--variant", choices=["mnist", "cifar10"], default="mnist")
+    ap.add_argument("--variant", choices=sorted(VARIANTS), default="mnist")
+    ap.add_argument("--amp", action="store_true", help="fp16 autocast + GradScaler (cifar10.py:440,458-467)")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
     ap.add_argument("--lr", type=float, default=1e-3)
@@ -90,8 +111,13 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     torch.manual_seed(0)                                  # identical initial weights on every rank
-    classes = 10
-    model = (MnistLike() if a.variant == "mnist" else Cifar10Like()).to(dev)
+    make, _, classes = VARIANTS[a.variant]
+    model = make().to(dev)
+    if a.variant == "emotion_model":        # PDELayer's default parameters exceed the explicit stability limit
+        with torch.no_grad():
+            for n, v in dict(alpha_w1=0.05, alpha_w2=0.02, alpha_w3=-0.01, beta_w1=0.04, beta_w2=0.015, beta_w3=0.01).items():
+                getattr(model.pde, n).fill_(v)
+    scaler = torch.amp.GradScaler("cuda", enabled=a.amp)
     templates = synthetic_task(a.variant, classes, torch.Generator().manual_seed(7)).to(dev)
     opt = torch.optim.AdamW(model.parameters(), lr=a.lr, weight_decay=1e-4)
     sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=a.steps)
@@ -104,13 +130,16 @@ def main():
         labels = torch.randint(0, classes, (a.batch,), generator=gen, device=dev)
         x = templates[labels] + 1.0 * torch.randn(a.batch, *templates.shape[1:], generator=gen, device=dev)
         opt.zero_grad(set_to_none=True)
-        out = model(x)
-        loss = crit(out, labels)
-        loss.backward()
+        with torch.autocast("cuda", dtype=torch.float16, enabled=a.amp):
+            out = model(x)
+            loss = crit(out, labels)
+        scaler.scale(loss).backward()
         if bucket is not None:
-            bucket.allreduce(average=True)               # ONE collective per step
+            bucket.allreduce(average=True)               # ONE collective per step (of the scaled gradients)
+        scaler.unscale_(opt)
         torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
-        opt.step()
+        scaler.step(opt)
+        scaler.update()
         sched.step()
         if step % a.log_every == 0 or step == a.steps - 1:
             acc = (out.argmax(1) == labels).float().mean().item()

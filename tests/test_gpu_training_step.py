@@ -18,11 +18,12 @@ def _load():
     return mod
 
 
-@pytest.mark.parametrize("variant", ["mnist", "cifar10"])
-def test_training_reduces_loss(variant, monkeypatch):
+@pytest.mark.parametrize("variant,amp", [("mnist", False), ("cifar10", False), ("cifar10_noconv", True), ("svhn_model", False),
+                                         ("fashion_model", False)])
+def test_training_reduces_loss(variant, amp, monkeypatch):
     mod = _load()
     monkeypatch.setattr(sys, "argv", ["train_synthetic.py", "--variant", variant, "--steps", "60", "--batch", "64",
-                                      "--log-every", "59"])
+                                      "--log-every", "59"] + (["--amp"] if amp else []))
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         monkeypatch.delenv(k, raising=False)
     log = mod.main()
