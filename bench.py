@@ -237,6 +237,9 @@ def main():
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the per-config legs (cfg1, cfg3, cfg4, cfg5)")
     ap.add_argument("--cpu-sample", type=int, default=160, help="upper bound of the CPU baseline sample (samples)")
+    ap.add_argument("--rehearse-one-device", action="store_true",
+                    help="developer rehearsal of the multi-rank path on a ONE-GPU box: every rank uses cuda:0 and the "
+                         "collectives run over gloo (RCCL refuses two ranks on one device); timings are meaningless")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -258,12 +261,17 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if a.rehearse_one_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     rccl_ws = 1
     if dist_on:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if a.rehearse_one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         rccl_ws = dist.get_world_size()
 
     import cnn_with_pde_amd as P
