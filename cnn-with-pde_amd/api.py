@@ -8,8 +8,9 @@ from .layers import (MnistDiffusionLayer, FashionDiffusionLayer, SvhnDiffusionLa
                      LearnableDiffusionLayer, ImprovedDiffusionLayer, PDELayer)
 from . import models
 from .models import (MnistPDEClassifier, FashionPDEClassifier, SvhnPDEClassifier, SpatialAttention, MultiScaleExtractor,
-                     EnhancedFC, CIFAR10PDENoConv, DiffusionPair, TinyImageNetClassifier, EmotionDiffusionClassifier,
-                     diffuse_shared_input)
+                     EnhancedFC, CIFAR10PDENoConv, SymmetricLayer, ParabolicBlock, HamiltonianBlock, HybridPDEExtractor,
+                     NonConvSpatialAttention, HybridClassifierHead, CIFAR10HybridPDEModel, hybrid_pde_regularization,
+                     TinyImageNetClassifier, EmotionDiffusionClassifier, diffuse_shared_input)
 
 #: (reference script, reference class name) -> class here
 REFERENCE_CLASSES = {
@@ -27,6 +28,13 @@ REFERENCE_CLASSES = {
     ("cifar10", "MultiScaleExtractor"): MultiScaleExtractor,
     ("cifar10", "EnhancedFC"): EnhancedFC,
     ("cifar10", "CIFAR10PDENoConv"): CIFAR10PDENoConv,
+    ("cifar_2version", "SymmetricLayer"): SymmetricLayer,
+    ("cifar_2version", "ParabolicBlock"): ParabolicBlock,
+    ("cifar_2version", "HamiltonianBlock"): HamiltonianBlock,
+    ("cifar_2version", "HybridPDEExtractor"): HybridPDEExtractor,
+    ("cifar_2version", "NonConvSpatialAttention"): NonConvSpatialAttention,
+    ("cifar_2version", "PDEClassifier"): HybridClassifierHead,
+    ("cifar_2version", "CIFAR10HybridPDEModel"): CIFAR10HybridPDEModel,
     ("tiny_imagenet", "ImprovedTinyImageNetClassifier"): TinyImageNetClassifier,
     ("emotion_recognition", "DiffusionClassifier"): EmotionDiffusionClassifier,
 }
@@ -41,5 +49,7 @@ __all__ = ["PdeError", "LIB_PATH", "Sweep", "adi_schedule", "adi_diffuse", "adi_
            "jacobi_diffuse", "timing_enable", "timing_read", "MnistDiffusionLayer", "FashionDiffusionLayer",
            "SvhnDiffusionLayer", "EnhancedDiffusionLayer", "LearnableDiffusionLayer", "ImprovedDiffusionLayer",
            "PDELayer", "models", "MnistPDEClassifier", "FashionPDEClassifier", "SvhnPDEClassifier", "SpatialAttention",
-           "MultiScaleExtractor", "EnhancedFC", "CIFAR10PDENoConv", "DiffusionPair", "TinyImageNetClassifier",
+           "MultiScaleExtractor", "EnhancedFC", "CIFAR10PDENoConv", "SymmetricLayer", "ParabolicBlock", "HamiltonianBlock",
+           "HybridPDEExtractor", "NonConvSpatialAttention", "HybridClassifierHead", "CIFAR10HybridPDEModel",
+           "hybrid_pde_regularization", "TinyImageNetClassifier",
            "EmotionDiffusionClassifier", "diffuse_shared_input", "REFERENCE_CLASSES", "library_version", "shard_range", "shard_batch", "GradBucket"]

@@ -12,7 +12,11 @@ as they are in the reference (out of scope as code to accel
     cifar10.MultiScaleExtractor         :248-282           MultiScaleExtractor   (three layers, ONE launch per pass)
     cifar10.EnhancedFC                  :286-314           EnhancedFC
     cifar10.CIFAR10PDENoConv            :318-361           CIFAR10PDENoConv
-    cifar_2version.HybridPDEExtractor   :261-302           DiffusionPair         (its two diffusion branches only)
+    cifar_2version.SymmetricLayer / ParabolicBlock / HamiltonianBlock :190-258   same names (plain torch, rocBLAS)
+    cifar_2version.HybridPDEExtractor   :261-302           HybridPDEExtractor    (two diffusion layers in ONE launch per pass)
+    cifar_2version.NonConvSpatialAttention / PDEClassifier / CIFAR10HybridPDEModel :305-412
+                                                           NonConvSpatialAttention / HybridClassifierHead / CIFAR10HybridPDEModel
+    cifar_2version.hybrid_pde_regularization :415-436      hybrid_pde_regularization
     tiny_imagenet.ImprovedTinyImageNetClassifier :237-329  TinyImageNetClassifier
     emotion_recognition.DiffusionClassifier :170-195       EmotionDiffusionClassifier
 """
@@ -27,8 +31,9 @@ from .layers import (MnistDiffusionLayer, FashionDiffusionLayer, SvhnDiffusionLa
                      LearnableDiffusionLayer, ImprovedDiffusionLayer, PDELayer)
 
 __all__ = ["MnistPDEClassifier", "FashionPDEClassifier", "SvhnPDEClassifier", "SpatialAttention", "MultiScaleExtractor",
-           "EnhancedFC", "CIFAR10PDENoConv", "DiffusionPair", "TinyImageNetClassifier", "EmotionDiffusionClassifier",
-           "diffuse_shared_input"]
+           "EnhancedFC", "CIFAR10PDENoConv", "SymmetricLayer", "ParabolicBlock", "HamiltonianBlock", "HybridPDEExtractor",
+           "NonConvSpatialAttention", "HybridClassifierHead", "CIFAR10HybridPDEModel", "hybrid_pde_regularization",
+           "TinyImageNetClassifier", "EmotionDiffusionClassifier", "diffuse_shared_input"]
 
 
 def diffuse_shared_input(layers, x, weights=None, plane_sums=False):
@@ -209,21 +214,152 @@ class CIFAR10PDENoConv(nn.Module):
         return self.classifier(pooled.view(pooled.size(0), -1))
 
 
-class DiffusionPair(nn.Module):
-    """The two diffusion branches of cifar_2version.HybridPDEExtractor (:269-270, :287-288): LearnableDiffusionLayers
-    with (dt, steps) = (0.001, 8) and (0.002, 5) on the same input, one launch per pass.  (The Parabolic and
-    Hamiltonian branches of that extractor are dense 3072 x 3072 layers: SURVEY.md §8f-4, not built.)"""
+class SymmetricLayer(nn.Module):
+    """cifar_2version.py:190-220 (Ruthotto & Haber): F(Y) = -K^T act(BN(K Y)) on the flattened image, K a dense
+    (C*H*W)^2 matrix initialised near the identity.  Plain torch (rocBLAS GEMMs), as in the reference — SURVEY §8f-4:
+    dense contractions, not the stencil path; no custom kernel here."""
+
+    def __init__(self, channels, spatial_size, activation="relu"):
+        super().__init__()
+        self.channels, self.spatial_size = channels, spatial_size
+        self.feature_dim = channels * spatial_size * spatial_size
+        self.K = nn.Linear(self.feature_dim, self.feature_dim, bias=False)
+        self.norm = nn.BatchNorm1d(self.feature_dim)
+        self.activation = {"relu": nn.ReLU, "tanh": nn.Tanh}.get(activation, nn.Identity)()
+        nn.init.eye_(self.K.weight)
+        self.K.weight.data += torch.randn_like(self.K.weight) * 0.01
+
+    def forward(self, Y):
+        B = Y.shape[0]
+        h = self.activation(self.norm(self.K(Y.reshape(B, -1))))
+        return (-(h @ self.K.weight)).view_as(Y)
+
+
+class ParabolicBlock(nn.Module):
+    """cifar_2version.py:223-236: forward Euler on dY/dt = F_sym(Y)."""
+
+    def __init__(self, channels, spatial_size, num_steps=3, dt=1.0):
+        super().__init__()
+        self.num_steps, self.dt = num_steps, dt
+        self.symmetric_layer = SymmetricLayer(channels, spatial_size)
+        print(f"Parabolic Block: {num_steps} steps, dt={dt}")
+
+    def forward(self, Y):
+        for _ in range(self.num_steps):
+            Y = Y + self.dt * self.symmetric_layer(Y)
+        return Y
+
+
+class HamiltonianBlock(nn.Module):
+    """cifar_2version.py:239-258: symplectic steps Y += dt*(-F_Y(Z)); Z -= dt*F_Z(Y), Z starting at zero."""
+
+    def __init__(self, channels, spatial_size, num_steps=3, dt=1.0):
+        super().__init__()
+        self.num_steps, self.dt = num_steps, dt
+        self.F_Y = SymmetricLayer(channels, spatial_size)
+        self.F_Z = SymmetricLayer(channels, spatial_size)
+        print(f"Hamiltonian Block: {num_steps} steps, dt={dt}")
+
+    def forward(self, Y):
+        Z = torch.zeros_like(Y)
+        for _ in range(self.num_steps):
+            Y = Y - self.dt * self.F_Y(Z)
+            Z = Z - self.dt * self.F_Z(Y)
+        return Y
+
+
+class HybridPDEExtractor(nn.Module):
+    """cifar_2version.py:261-302: two LearnableDiffusionLayers (one launch per pass), a Parabolic and a Hamiltonian
+    block on the same input, softmax-weighted sum, BatchNorm2d."""
 
     def __init__(self, input_size=32, channels=3):
         super().__init__()
         self.diffusion1 = LearnableDiffusionLayer(input_size, channels, dt=0.001, num_steps=8)
         self.diffusion2 = LearnableDiffusionLayer(input_size, channels, dt=0.002, num_steps=5)
-        self.combination_weights = nn.Parameter(torch.ones(2) / 2)
+        self.parabolic = ParabolicBlock(channels, input_size, num_steps=4, dt=0.5)
+        self.hamiltonian = HamiltonianBlock(channels, input_size, num_steps=3, dt=0.8)
+        self.combination_weights = nn.Parameter(torch.ones(4) / 4)
+        self.feature_norm = nn.BatchNorm2d(channels)
 
     def forward(self, x):
         w = F.softmax(self.combination_weights, dim=0)
-        combined, (y1, y2) = diffuse_shared_input([self.diffusion1, self.diffusion2], x, w)
-        return combined, y1, y2
+        _, (d1, d2) = diffuse_shared_input([self.diffusion1, self.diffusion2], x)
+        par, ham = self.parabolic(x), self.hamiltonian(x)
+        combined = self.feature_norm(w[0] * d1 + w[1] * d2 + w[2] * par + w[3] * ham)
+        return combined, d1, d2, par, ham
+
+
+class NonConvSpatialAttention(nn.Module):
+    """cifar_2version.py:305-328: an element-wise gate from a three-layer MLP of the flattened x + pos_embed."""
+
+    def __init__(self, channels, spatial_size):
+        super().__init__()
+        self.channels, self.spatial_size = channels, spatial_size
+        self.feature_dim = d = channels * spatial_size * spatial_size
+        self.pos_embed = nn.Parameter(torch.randn(1, channels, spatial_size, spatial_size) * 0.02)
+        self.attention_net = nn.Sequential(nn.Linear(d, d // 4), nn.ReLU(), nn.Linear(d // 4, d // 8), nn.ReLU(),
+                                           nn.Linear(d // 8, d), nn.Sigmoid())
+
+    def forward(self, x):
+        return x * self.attention_net((x + self.pos_embed).reshape(x.shape[0], -1)).view_as(x)
+
+
+class HybridClassifierHead(nn.Module):
+    """cifar_2version.PDEClassifier :331-366: 1024-512-256-128 Linear / BatchNorm1d / ReLU / Dropout stack."""
+
+    def __init__(self, input_dim, num_classes=10, dropout_rate=0.4):
+        super().__init__()
+        mods, prev = [], input_dim
+        for i, h in enumerate((1024, 512, 256, 128)):
+            mods += [nn.Linear(prev, h), nn.BatchNorm1d(h), nn.ReLU(inplace=True),
+                     nn.Dropout(dropout_rate // 2 if i == 3 else dropout_rate)]
+            prev = h
+        mods.append(nn.Linear(prev, num_classes))
+        self.classifier = nn.Sequential(*mods)
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.kaiming_normal_(m.weight)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+
+    def forward(self, x):
+        return self.classifier(x)
+
+
+class CIFAR10HybridPDEModel(nn.Module):
+    """cifar_2version.py:369-412: HybridPDEExtractor, element-wise attention, BatchNorm2d, 8x8 average and max pooling,
+    classifier on 384 features."""
+
+    def __init__(self, dropout_rate=0.4):
+        super().__init__()
+        self.feature_extractor = HybridPDEExtractor(input_size=32, channels=3)
+        self.attention = NonConvSpatialAttention(channels=3, spatial_size=32)
+        self.adaptive_avg_pool = nn.AdaptiveAvgPool2d((8, 8))
+        self.adaptive_max_pool = nn.AdaptiveMaxPool2d((8, 8))
+        self.feature_bn = nn.BatchNorm2d(3)
+        self.classifier = HybridClassifierHead(input_dim=384, num_classes=10, dropout_rate=dropout_rate)
+
+    def forward(self, x):
+        feats = self.feature_bn(self.attention(self.feature_extractor(x)[0]))
+        pooled = torch.cat([self.adaptive_avg_pool(feats), self.adaptive_max_pool(feats)], dim=1)
+        return self.classifier(pooled.view(pooled.size(0), -1))
+
+
+def hybrid_pde_regularization(model, alpha1=1e-4, alpha2=1e-4, alpha3=1e-6):
+    """cifar_2version.py:415-436: penalties selected by parameter NAME (which is why the layers keep the
+    reference's names): squared L2 on alpha_base / beta_base and on K.weight, squared Frobenius distance of
+    channel_mixing from the identity, L1 on combination_weights."""
+    reg = 0.0
+    for name, p in model.named_parameters():
+        if "alpha_base" in name or "beta_base" in name:
+            reg = reg + alpha3 * p.pow(2).sum()
+        elif "channel_mixing" in name:
+            reg = reg + alpha2 * (p - torch.eye(p.size(0), device=p.device)).pow(2).sum()
+        elif "K.weight" in name:
+            reg = reg + alpha2 * p.pow(2).sum()
+        elif "combination_weights" in name:
+            reg = reg + alpha1 * p.abs().sum()
+    return reg
 
 
 class _BasicBlock(nn.Module):

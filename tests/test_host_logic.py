@@ -117,3 +117,37 @@ def test_shard_range_covers_batch():
             assert all(a[1] == b[0] for a, b in zip(got, got[1:]))
             sizes = [e - b for b, e in got]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_counterpart_models_keep_the_reference_names():
+    """CPU: every counterpart model constructs, its parameter names are the reference's (the model fixtures made from
+    the reference's own modules list them), and the name-selected regulariser sees the parameters it is meant to."""
+    import contextlib
+    import io
+    import golden_util as G
+    import cnn_with_pde_amd as P
+    for name in G.names(directory=G.MODEL_DIR):
+        g = G.Golden(name, G.MODEL_DIR)
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = P.REFERENCE_CLASSES[(g.script, g.cls)](**g.ctor)
+        assert {n for n, _ in model.named_parameters()} == set(g.params), name
+        for n, p in model.named_parameters():
+            assert tuple(p.shape) == tuple(g.params[n].shape), (name, n)
+    with contextlib.redirect_stdout(io.StringIO()):
+        models = [P.MnistPDEClassifier(), P.FashionPDEClassifier(), P.CIFAR10PDENoConv(), P.EmotionDiffusionClassifier(),
+                  P.HybridPDEExtractor(input_size=8, channels=3)]
+    assert "diff.alpha_base" in dict(models[0].named_parameters())
+    assert "feature_extractor.pde2.channel_mixing" in dict(models[2].named_parameters())
+    hyb = models[4]
+    reg = P.hybrid_pde_regularization(hyb, 1e-4, 1e-4, 1e-6)
+    want = 0.0
+    for n, p in hyb.named_parameters():
+        if n.endswith("alpha_base") or n.endswith("beta_base"):
+            want += 1e-6 * float(torch.norm(p, p=2) ** 2)
+        elif n.endswith("channel_mixing"):
+            want += 1e-4 * float(torch.norm(p - torch.eye(3), p="fro") ** 2)
+        elif n.endswith("K.weight"):
+            want += 1e-4 * float(torch.norm(p, p=2) ** 2)
+        elif n.endswith("combination_weights"):
+            want += 1e-4 * float(torch.norm(p, p=1))
+    assert abs(float(reg) - want) <= 1e-6 * want

@@ -147,6 +147,15 @@ def models():
     make_model("model_cifar10_multiscale_default", "cifar10", "MultiScaleExtractor", {"input_size": 32, "channels": 3},
                (2, 3, 32, 32), 82)
 
+    # cifar_2version.HybridPDEExtractor at 8x8 (its dense K matrices are (C*H*W)^2: 192^2 here, 3072^2 at 32x32):
+    # two Lie-split diffusion layers + Parabolic + Hamiltonian blocks + softmax combination + BatchNorm2d (eval)
+    def live2(m, g):
+        live(m, g)
+        with torch.no_grad():
+            m.combination_weights.copy_(torch.tensor([0.3, -0.2, 0.1, 0.4]))
+    make_model("model_cifar2_hybrid_8", "cifar_2version", "HybridPDEExtractor", {"input_size": 8, "channels": 3},
+               (4, 3, 8, 8), 83, tweak=live2)
+
 
 def main():
     os.makedirs(OUT, exist_ok=True)
