@@ -502,6 +502,17 @@ int publish_kmax(const float* kmax_dev, float* kmax_host, void* event, int n, hi
     return PDE_OK;
 }
 
+// Strang schedules as the reference builds them (mnist_test.py:55-63): the second x sweep of a step and the first of
+// the next are at the same time with the same increment, i.e. have identical coefficient records
+bool strang_pairs_identical(const PdeAdiDesc* d) {
+    if (d->num_sweeps % 3) return false;
+    for (int s = 2; s + 1 < d->num_sweeps; s += 3) {
+        const PdeSweep &p = d->sweep[s], &q = d->sweep[s + 1];
+        if (p.axis != PDE_AXIS_X || q.axis != PDE_AXIS_X || p.t != q.t || p.delta != q.delta || p.h2 != q.h2) return false;
+    }
+    return true;
+}
+
 // which compile-time step pattern the schedule follows
 int split_of(const PdeAdiDesc* d) {
     const int S = d->num_sweeps;
@@ -569,6 +580,7 @@ int launch_fwd_sweeps(const PdeAdiDesc* d, const void* u, void* y, const float* 
     sa.G = groups_per_channel(d, kWaves * kJFwd, 16 / kWaves);
     sa.one_eps = 1.0f + d->eps;
     sa.xcd_map = use_xcd_map(d);
+    sa.pair_x = (split_of(d) == kSplitStrang && strang_pairs_identical(d)) ? 1 : 0;
     const size_t lds = (size_t)(kRing * kRecFwdPad + kWaves * kImage) * sizeof(float);
     return dispatch_fwd(d, split_of(d), sa, sa.G * d->C, lds, st);
 }
@@ -618,6 +630,7 @@ int launch_bwd_sweeps(const PdeAdiDesc* d, const void* gy, const void* y, const 
     sa.one_eps = 1.0f + d->eps;
     sa.gu_scale = (float)pow(1.0 + (double)d->eps, -(double)d->num_sweeps);
     sa.acc_part = accumulate;
+    sa.pair_x = (split_of(d) == kSplitStrang && strang_pairs_identical(d)) ? 1 : 0;
     sa.dbg = dbg;
     int rc = PDE_OK;
     if (nck) {

@@ -65,6 +65,8 @@ struct SweepArgs {
     float one_eps;          // 1 + eps
     float gu_scale;         // bwd: (1+eps)^-S
     int acc_part;           // bwd: add the partial gradient sums to what `part` holds (per-step launches)
+    int pair_x;             // Strang schedules: the last x sweep of a step and the first of the next have the SAME record
+                            // (same time, same increment): its rows are loaded from LDS once for the two sweeps
     void* dbg;              // diagnostic builds only
 };
 
@@ -419,12 +421,9 @@ __device__ __forceinline__ void load_half(const float* src, float (&dst)[M]) {
 
 // ---- forward: (A + eps I) x = d on J planes, two-sided ---------------------------------
 template <int M, int J>
-__device__ __forceinline__ void solve_fwd(typename Pack<J>::P (&v)[M], const float* rec, int l, int hf) {
+__device__ __forceinline__ void solve_fwd_rows(typename Pack<J>::P (&v)[M], const float (&e)[M], const float (&inv)[M], float jn,
+                                               int hf) {
     using P = typename Pack<J>::P;
-    float e[M], inv[M];
-    load_half<M>(rec + kF_E + l * kLineStride + hf * kHalfPad, e);
-    load_half<M>(rec + kF_Inv + l * kLineStride + hf * kHalfPad, inv);
-    const float jn = rec[kF_Jn + l];
     // elimination from my end inwards: D_k = d_k*inv_k + e_k*D_{k-1}
 #pragma unroll
     for (int k = 0; k < M; ++k) {
@@ -439,6 +438,18 @@ __device__ __forceinline__ void solve_fwd(typename Pack<J>::P (&v)[M], const flo
     // substitution outwards: x_k = D_k + e_k*x_{k+1}
 #pragma unroll
     for (int k = M - 2; k >= 0; --k) v[k] = pk_fma(pk_bc<P>(e[k]), v[k + 1], v[k]);
+}
+template <int M>
+__device__ __forceinline__ void load_fwd_rows(const float* rec, int l, int hf, float (&e)[M], float (&inv)[M], float& jn) {
+    load_half<M>(rec + kF_E + l * kLineStride + hf * kHalfPad, e);
+    load_half<M>(rec + kF_Inv + l * kLineStride + hf * kHalfPad, inv);
+    jn = rec[kF_Jn + l];
+}
+template <int M, int J>
+__device__ __forceinline__ void solve_fwd(typename Pack<J>::P (&v)[M], const float* rec, int l, int hf) {
+    float e[M], inv[M], jn;
+    load_fwd_rows<M>(rec, l, hf, e, inv, jn);
+    solve_fwd_rows<M, J>(v, e, inv, jn, hf);
 }
 
 __device__ __forceinline__ int ck_slot(const unsigned long long (&ck)[2], int s) {
@@ -541,11 +552,14 @@ __global__ __launch_bounds__(kThreads) void adi_fwd_kernel(SweepArgs a) {
         __syncthreads();
     }
 
+    // coefficient rows of the current sweep: the first x sweep of a Strang step keeps those of the previous step's last
+    // one (same record, see SweepArgs::pair_x) instead of reading them from LDS again
+    float ce[M], cinv[M], cjn = 0.f;
     for (int q = g; q < nchunk; q += a.G) {
         typename Pack<J>::P v[M];
         if constexpr (J > 2) load_planes_seq<N, J, IO>(u, q, wave, lane, l, hf, a.B, a.C, c, T, v);   // 16, not 16*J, registers in flight
         else load_planes<N, J, IO>(u, q, wave, lane, l, hf, a.B, a.C, c, T, v);
-        auto sweep = [&](auto AXC, int s) {
+        auto sweep = [&](auto AXC, int s, auto TWINC) {
             constexpr int AX = decltype(AXC)::value;
             int sp = s + lag + 1;                         // sweep of the item staged in this interval
             if (sp >= a.S) sp -= a.S;
@@ -556,7 +570,8 @@ __global__ __launch_bounds__(kThreads) void adi_fwd_kernel(SweepArgs a) {
             const float* rec = cbuf + cur * kRecFwdPad;
             const int axs = (AX >= 0) ? AX : tab->axis[s];
             if (axs == PDE_AXIS_Y) relayout_all<N, J>(v, T, l, hf);
-            solve_fwd<M, J>(v, rec, l, hf);
+            if (!(decltype(TWINC)::value && a.pair_x != 0 && s != 0)) load_fwd_rows<M>(rec, l, hf, ce, cinv, cjn);
+            solve_fwd_rows<M, J>(v, ce, cinv, cjn, hf);
             if (axs == PDE_AXIS_Y) relayout_all<N, J>(v, T, l, hf);
             if (a.ckpt != nullptr && ck_bit(a.ck, s)) {   // backward pre-pass: park this state (fp32)
                 float* slot = a.ckpt + (size_t)ck_slot(a.ck, s) * a.B * a.C * plane;
@@ -568,17 +583,17 @@ __global__ __launch_bounds__(kThreads) void adi_fwd_kernel(SweepArgs a) {
         };
         if constexpr (SPLIT == kSplitStrang) {
             for (int s = 0; s < a.S; s += 3) {
-                sweep(std::integral_constant<int, PDE_AXIS_X>{}, s);
-                sweep(std::integral_constant<int, PDE_AXIS_Y>{}, s + 1);
-                sweep(std::integral_constant<int, PDE_AXIS_X>{}, s + 2);
+                sweep(std::integral_constant<int, PDE_AXIS_X>{}, s, std::true_type{});       // twin of the sweep before it
+                sweep(std::integral_constant<int, PDE_AXIS_Y>{}, s + 1, std::false_type{});
+                sweep(std::integral_constant<int, PDE_AXIS_X>{}, s + 2, std::false_type{});
             }
         } else if constexpr (SPLIT == kSplitLie) {
             for (int s = 0; s < a.S; s += 2) {
-                sweep(std::integral_constant<int, PDE_AXIS_X>{}, s);
-                sweep(std::integral_constant<int, PDE_AXIS_Y>{}, s + 1);
+                sweep(std::integral_constant<int, PDE_AXIS_X>{}, s, std::false_type{});
+                sweep(std::integral_constant<int, PDE_AXIS_Y>{}, s + 1, std::false_type{});
             }
         } else {
-            for (int s = 0; s < a.S; ++s) sweep(std::integral_constant<int, -1>{}, s);
+            for (int s = 0; s < a.S; ++s) sweep(std::integral_constant<int, -1>{}, s, std::false_type{});
         }
         if (y != nullptr) store_planes<N, J, IO>(y, q, wave, lane, l, hf, a.B, a.C, c, T, v);
     }
@@ -769,13 +784,18 @@ __device__ __forceinline__ void adi_bwd_body(const SweepArgs& a, int blk) {
     // (all chunks, sweeps in decreasing time):  sum_i tau_i G_i = sum_i (tau_i - tau_{i+1}) R_i
     // with R_i the running sum of g.q and tau_{i+1} the time of the next processed sweep of
     // the same axis (0 after the very last one).  So Ax/Ay double as R and are never reset.
-    auto body = [&](auto AXC, int axr, int s, const float* rec, float dts) __attribute__((always_inline)) {
+    // coefficient rows of the current sweep; an x sweep that follows its twin (see pair_x) keeps them: every dword an
+    // LDS read returns costs the SIMD ~6 cycles (tools/ubench/simd_share.hip), the three rows of a sweep are 37 % of an
+    // x sweep's time
+    float ce[M], cinv[M], ckap[M], cjn = 0.f;
+    auto body = [&](auto AXC, int axr, int s, const float* rec, float dts, auto TWINC) __attribute__((always_inline)) {
         constexpr int AX = decltype(AXC)::value;
         const int axs = (AX >= 0) ? AX : axr;
         if (more && s == (axs == PDE_AXIS_Y ? first_y : first_x)) dts -= (axs == PDE_AXIS_Y ? tlast_y : tlast_x);
-        float ce[M], cinv[M], ckap[M];
         const float* crow = rec + l * kLineStride + hf * kHalfPad;
-        const float cjn = rec[kB_Jn + l];
+        // the newest sweep of my chunk has no twin before it (the previous item belongs to another chunk)
+        const bool twin = decltype(TWINC)::value && a.pair_x != 0 && s != a.S - 1;
+        if (!twin) cjn = rec[kB_Jn + l];
         if (axs == PDE_AXIS_Y) {
             relayout_all<N, J>(r, T, l, hf);
             load_half<M>(crow + kB_E, ce);
@@ -791,10 +811,12 @@ __device__ __forceinline__ void adi_bwd_body(const SweepArgs& a, int blk) {
         } else {
             // partner half's innermost state: issue the exchange now, use it after the solve
             const P xin = pk_map(x[M - 1], [&](float z) { return xchg_half(z, hf); });
-            load_half<M>(crow + kB_E, ce);
-            load_half<M>(crow + kB_Inv, cinv);
+            if (!twin) {
+                load_half<M>(crow + kB_E, ce);
+                load_half<M>(crow + kB_Inv, cinv);
+            }
             solve_adj<M, J>(r, ce, cinv, cjn, hf);
-            load_half<M>(crow + kB_KapX, ckap);
+            if (!twin) load_half<M>(crow + kB_KapX, ckap);
             state_x<M, J, MASKED>(r, x, Ax, xin, ckap, rec, l, hf, a.smooth3);
             if (dts != 0.f) {
 #pragma unroll
@@ -860,7 +882,10 @@ __device__ __forceinline__ void adi_bwd_body(const SweepArgs& a, int blk) {
                         if constexpr (pos == 0) {
                             if (s == a.S - 1) chunk_in();
                         }
-                        body(std::integral_constant<int, AX>{}, AX, s, cbuf + (size_t)slot * RECP, tab->dts[s]);
+                        // Strang, newest sweep of a step (an x sweep): its record equals that of the sweep processed just
+                        // before it, the first x sweep of the next step
+                        body(std::integral_constant<int, AX>{}, AX, s, cbuf + (size_t)slot * RECP, tab->dts[s],
+                             std::bool_constant<(SPLIT == kSplitStrang && pos == 0 && !MASKED)>{});
                         if constexpr (pos == SPS - 1) {
                             if (s == 0) {
                                 chunk_out();
@@ -906,7 +931,7 @@ __device__ __forceinline__ void adi_bwd_body(const SweepArgs& a, int blk) {
                 const int snext = (s > 0) ? s - 1 : a.S - 1;
                 const bool pre = (s > 0) || more;
                 if (pre) stage_load<REC>(a.coef + ((size_t)snext * a.C + c) * kRecStride + kBwdOff, tid, stg);
-                body(std::integral_constant<int, -1>{}, tab->axis[s], s, cbuf + (n & 1) * RECP, tab->dts[s]);
+                body(std::integral_constant<int, -1>{}, tab->axis[s], s, cbuf + (n & 1) * RECP, tab->dts[s], std::false_type{});
                 if (pre) stage_store<REC>(cbuf + ((n + 1) & 1) * RECP, tid, stg);
                 __syncthreads();
                 ++n;
