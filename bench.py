@@ -341,13 +341,22 @@ def main():
                          "note": "per GPU: samples/s x 20 B/element (whole step incl. launch gaps and small kernels)"},
         }
         if valu:
-            # the resource these kernels actually saturate first: a wave64 fp32 VALU instruction
-            # holds its SIMD for 4 cycles; 1024 SIMDs at 2.4 GHz
-            floor_b = valu["adi_bwd_kernel"] * 4 / 1024 / 2.4e9 * 1e3
-            floor_f = valu["adi_fwd_kernel"] * 4 / 1024 / 2.4e9 * 1e3
-            out["valu_issue"] = {"note": "SQ_INSTS_VALU per launch (rocprofv3 --pmc, profiles/) x 4 cycles / 1024 SIMDs / 2.4 GHz",
-                                 "adi_bwd_kernel": {"floor_ms": floor_b, "frac": floor_b / bwd_ms},
-                                 "adi_fwd_kernel": {"floor_ms": floor_f, "frac": floor_f / fwd_ms}}
+            # the second ceiling: VALU issue.  A SIMD takes one wave64 fp32 instruction per ~2 cycles from
+            # two or more waves (tools/ubench/sweep_pk.hip: 2.3 with two, 1.6 with three), one wave issues at most one
+            # per ~4.3 cycles; the backward has two waves per SIMD (246 VGPRs), the forward four.  1024 SIMDs at 2.4 GHz.
+            def floors(n_inst, waves_per_simd):
+                simd = n_inst * 2.0 / 1024 / 2.4e9 * 1e3
+                per_wave = n_inst * 4.3 / waves_per_simd / 1024 / 2.4e9 * 1e3
+                return simd, max(simd, per_wave)
+            sb, wb = floors(valu["adi_bwd_kernel"], 2)
+            sf, wf = floors(valu["adi_fwd_kernel"], 4)
+            out["valu_issue"] = {"note": "SQ_INSTS_VALU per launch (rocprofv3 --pmc, profiles/) at the SIMD's rate (2 cycles per "
+                                         "instruction) and at the per-wave issue limit (4.3 cycles, waves per SIMD: backward 2, "
+                                         "forward 4); frac = floor / measured launch time",
+                                 "adi_bwd_kernel": {"floor_ms_simd_rate": sb, "frac_simd_rate": sb / bwd_ms,
+                                                    "floor_ms_per_wave_limit": wb, "frac_per_wave_limit": wb / bwd_ms},
+                                 "adi_fwd_kernel": {"floor_ms_simd_rate": sf, "frac_simd_rate": sf / fwd_ms,
+                                                    "floor_ms_per_wave_limit": wf, "frac_per_wave_limit": wf / fwd_ms}}
 
     if not a.no_secondary:
         layer2 = build_layer(C, N, steps, dev, rank, mixing=True)
