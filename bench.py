@@ -149,7 +149,7 @@ def config_legs(dev, rank, world, dist_on, quick):
         u = torch.randn(*shape, generator=g).to(dtype).to(dev).requires_grad_(True)
         gy = torch.randn(*shape, generator=g).to(dtype).to(dev)
         flat = P.GradBucket(layer.parameters()) if dist_on else None
-        dt = timed(layer, u, gy, steps, 3, dist_on, flat)
+        dt = timed(layer, u, gy, steps, 10, dist_on, flat)      # the small legs are host-bound: let clocks and caches settle
         ms = dt / steps * 1e3
         gbs = u.numel() * bpe / (dt / steps) / 1e9            # per GPU
         if rank == 0:
@@ -207,7 +207,7 @@ def config_legs(dev, rank, world, dist_on, quick):
         out.backward(gx)
     res = {}
     for fused in (True, False):
-        for _ in range(5):
+        for _ in range(15):
             trio_step(fused)
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -74,7 +74,8 @@ namespace {
 // ------------------------------------------------------------------------------------
 struct FactorArgs {
     SweepTab* tab;
-    int* varying;           // [C] set to 1 when a clamp mask of the channel differs between sweeps (may be null)
+    int* varying;           // [C] 1 when a clamp mask of the channel differs between sweeps; followed in memory by the
+                            // per-(sweep, channel) partials this kernel writes: int dpart[S][C], float kpart[S][C]
     float t_first[2];       // time of the earliest sweep of each axis
     const float* ab;
     const float* bb;
@@ -116,9 +117,15 @@ __device__ __forceinline__ float clamp_theta(float th, const FactorArgs& a, bool
     return th;
 }
 
+constexpr int kFacLd = PDE_MAX_N + 1;     // LDS row stride of the staged parameter planes
+// ints reserved for the per-channel flags in front of the per-(sweep, channel) partials (64-int granules)
+__host__ __device__ inline int flag_ints(int C) { return (C + 63) / 64 * 64; }
+
 template <int N>
 __global__ __launch_bounds__(128) void adi_factor_kernel(FactorArgs a) {
     constexpr int m = N / 2;
+    __shared__ float fsm[2 * 2 * kFacLd * PDE_MAX_N];      // per wave: theta plane, pass-flag plane
+    __shared__ __attribute__((aligned(16))) float rsm[2 * kRecStride];   // per wave: the record, assembled before it is stored
     const int pairs = (a.C + 1) / 2;
     const int s = blockIdx.x / pairs;
     const int c = 2 * (blockIdx.x % pairs) + (threadIdx.x >> 6);           // one wave per channel of the pair
@@ -149,10 +156,14 @@ __global__ __launch_bounds__(128) void adi_factor_kernel(FactorArgs a) {
         }
     }
     float kmax_lane = 0.f;
+    int any_differs_w = 0;
     const PdeSweep sw = a.sweep[s];
     const bool xax = sw.axis == PDE_AXIS_X;
     if (c < a.C) {                                   // wave-uniform
-        float* rec = a.coef + ((size_t)s * a.C + c) * kRecStride;
+        // the record is assembled in LDS (every lane writes its half rows) and then stored with linear, fully
+        // coalesced 16-byte stores: half-row stores straight to memory (16 B per lane at a 144-byte stride) took 29 us
+        float* rec = rsm + (threadIdx.x >> 6) * kRecStride;
+        float* grec = a.coef + ((size_t)s * a.C + c) * kRecStride;
         float zero[m];
 #pragma unroll
         for (int k = 0; k < m; ++k) zero[k] = 0.f;
@@ -164,28 +175,49 @@ __global__ __launch_bounds__(128) void adi_factor_kernel(FactorArgs a) {
         const float* base = xax ? a.ab : a.bb;
         const float* slope = xax ? a.as : a.bs;
         const size_t cbase = (size_t)c * N * N;
-        const int st = xax ? 1 : N;                 // stride between consecutive unknowns of my line
-        const int o0 = xax ? ln * N : ln;
         const float third = 1.0f / 3.0f;
         const float one_eps = 1.0f + a.eps, r1e = 1.0f / one_eps;
-        // my unknowns: k = 0..m-1 at global index i(k) = hf ? N-1-k : k; raw theta also one step beyond my
+        // The wave first brings its channel's plane of theta = clamp(base + slope*t, eps[, max]) (mnist_test.py:33-42)
+        // and of the clamp pass-through flags into LDS with coalesced 16-byte loads (stride 33: a line is read along
+        // either axis without bank conflicts); a lane then picks its half line — and, for a y sweep, its half ROW and
+        // the rows above and below for the smoothing — from there.  (Per-lane 4-byte loads at a 128-byte lane stride
+        // straight from memory made this kernel 31 us.)
+        float* TH = fsm + (threadIdx.x >> 6) * (2 * kFacLd * PDE_MAX_N);
+        float* PS = TH + kFacLd * PDE_MAX_N;
+        bool differs = false;
+        {
+            const int wl = threadIdx.x & 63;
+            const float4* b4 = reinterpret_cast<const float4*>(base + cbase);
+            const float4* s4 = reinterpret_cast<const float4*>(slope + cbase);
+            for (int f = wl; f < N * N / 4; f += 64) {
+                const float4 bv = b4[f], sv = s4[f];
+                const int hh = (4 * f) / N, ww = (4 * f) % N;
+                const float bb[4] = {bv.x, bv.y, bv.z, bv.w}, ss[4] = {sv.x, sv.y, sv.z, sv.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    bool ps, ps0;
+                    const float t = clamp_theta(bb[q] + ss[q] * sw.t, a, ps);
+                    (void)clamp_theta(bb[q] + ss[q] * a.t_first[sw.axis], a, ps0);
+                    differs |= (ps != ps0);
+                    TH[hh * kFacLd + ww + q] = t;
+                    PS[hh * kFacLd + ww + q] = ps ? 1.0f : 0.0f;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // my unknowns: k = 0..m-1 at global index i(k) = hf ? N-1-k : k; theta also one step beyond my
         // inner end (index m or m-1) for the 3-tap smoothing
         float th[m + 1], pass[m];
-        bool differs = false;
-        // theta = clamp(base + slope*t, eps[, max])          mnist_test.py:33-42
 #pragma unroll
         for (int k = 0; k <= m; ++k) {
             const int i = hf ? N - 1 - k : k;
-            const float bs = base[cbase + o0 + i * st], sl = slope[cbase + o0 + i * st];
-            bool ps, ps0;
-            th[k] = clamp_theta(bs + sl * sw.t, a, ps);
-            if (k < m) {
-                (void)clamp_theta(bs + sl * a.t_first[sw.axis], a, ps0);
-                differs |= (ps != ps0);
-                pass[k] = ps ? 1.0f : 0.0f;
-            }
+            const int at = xax ? ln * kFacLd + i : i * kFacLd + ln;
+            th[k] = TH[at];
+            if (k < m) pass[k] = PS[at];
         }
-        if (differs && !idle && a.varying) atomicOr(&a.varying[c], 1);
+        // per-(sweep, channel) partial, combined by adi_flags_kernel: 1920 atomics on the ONE cache line that holds the
+        // 30 per-sweep maxima were 20 of this kernel's 29 us
+        any_differs_w = __any(differs ? 1 : 0) != 0 ? 1 : 0;
         float kap[m];
         if (a.smooth3) {                             // mnist_test.py:135-149 (replicate ends): prev/next along the line
 #pragma unroll
@@ -234,29 +266,56 @@ __global__ __launch_bounds__(128) void adi_factor_kernel(FactorArgs a) {
 #pragma unroll
             for (int k = 0; k < m; ++k) { kx[k] = kap[k] * r1e; mx[k] = pass[k]; }
         } else {
-            // y sweep: coefficient of row h = line along w, from beta directly (smoothing runs along h)
+            // y sweep: coefficient of row h = line along w (smoothing runs along h)
             const int h = ln;
             const int hm = h > 0 ? h - 1 : 0, hp = h + 1 < N ? h + 1 : N - 1;
 #pragma unroll
             for (int k = 0; k < m; ++k) {
                 const int w = hf ? N - 1 - k : k;
-                bool ps, pd;
-                float t0 = clamp_theta(base[cbase + h * N + w] + slope[cbase + h * N + w] * sw.t, a, ps);
-                if (a.smooth3) {
-                    const float tm = clamp_theta(base[cbase + hm * N + w] + slope[cbase + hm * N + w] * sw.t, a, pd);
-                    const float tp = clamp_theta(base[cbase + hp * N + w] + slope[cbase + hp * N + w] * sw.t, a, pd);
-                    t0 = (tm * third + t0 * third) + tp * third;
-                }
+                float t0 = TH[h * kFacLd + w];
+                if (a.smooth3) t0 = (TH[hm * kFacLd + w] * third + t0 * third) + TH[hp * kFacLd + w] * third;
                 kx[k] = ((t0 * sw.delta) / sw.h2) * r1e;
-                mx[k] = ps ? 1.0f : 0.0f;
+                mx[k] = PS[h * kFacLd + w];
             }
         }
         store_half_row<N>(row + kG_KapX, hf, idle ? zero : kx);
         store_half_row<N>(row + kG_MaskX, hf, idle ? zero : mx);
+        __builtin_amdgcn_wave_barrier();
+        static_assert(kRecStride % 4 == 0, "record is a whole number of 16-byte pieces");
+        const float4* src = reinterpret_cast<const float4*>(rec);
+        float4* dst = reinterpret_cast<float4*>(grec);
+        for (int f = threadIdx.x & 63; f < kRecStride / 4; f += 64) dst[f] = src[f];
     }
-    if (a.kmax) {                                    // per-sweep maximum coefficient: one atomic per wave
+    if (a.varying && c < a.C) {                      // my wave's (sweep, channel) partials: plain stores
         for (int o = 32; o > 0; o >>= 1) kmax_lane = fmaxf(kmax_lane, __shfl_xor(kmax_lane, o, 64));
-        if ((threadIdx.x & 63) == 0) atomicMax((unsigned int*)&a.kmax[s], __float_as_uint(kmax_lane));   // values are >= 0
+        if ((threadIdx.x & 63) == 0) {
+            int* dpart = a.varying + flag_ints(a.C);
+            float* kpart = reinterpret_cast<float*>(dpart + (size_t)a.S * a.C);
+            dpart[(size_t)s * a.C + c] = any_differs_w;
+            kpart[(size_t)s * a.C + c] = kmax_lane;
+        }
+    }
+}
+
+// second stage of the flags / maxima: one wave per sweep (kmax[s] = max over the channels), then one per channel
+// (varying[c] = OR over the sweeps): a few parallel loads and a wave reduction each — a single workgroup walking the
+// partials serially took 14 us
+__global__ __launch_bounds__(64) void adi_flags_kernel(int* varying, float* kmax, int S, int C) {
+    const int* dpart = varying + flag_ints(C);
+    const float* kpart = reinterpret_cast<const float*>(dpart + (size_t)S * C);
+    const int lane = threadIdx.x, b = blockIdx.x;
+    if (b < S) {
+        if (kmax == nullptr) return;
+        float m = 0.f;
+        for (int c = lane; c < C; c += 64) m = fmaxf(m, kpart[(size_t)b * C + c]);
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if (lane == 0) kmax[b] = m;
+    } else {
+        const int c = b - S;
+        int f = 0;
+        for (int s = lane; s < S; s += 64) f |= dpart[(size_t)s * C + c];
+        f = __any(f) ? 1 : 0;
+        if (lane == 0) varying[c] = f;
     }
 }
 
@@ -294,13 +353,6 @@ __global__ __launch_bounds__(64) void adi_kmax_kernel(FactorArgs a) {
     }
     for (int o = 32; o > 0; o >>= 1) km = fmaxf(km, __shfl_xor(km, o, 64));
     if (threadIdx.x == 0) atomicMax((unsigned int*)&a.kmax[s], __float_as_uint(km));   // coefficients are > 0
-}
-
-// one launch instead of two hipMemsetAsync (which become three fill kernels of ~4.5 us each)
-__global__ __launch_bounds__(256) void adi_zero_kernel(int* flags, int nflags, float* kmax, int nk) {
-    for (int i = threadIdx.x; i < nflags; i += 256) flags[i] = 0;
-    if (kmax)
-        for (int i = threadIdx.x; i < nk; i += 256) kmax[i] = 0.f;
 }
 
 // ---- parameter-gradient epilogue: one workgroup per channel ------------------------------
@@ -429,7 +481,9 @@ size_t coef_bytes(const PdeAdiDesc* d) {
     return align_up((size_t)d->num_sweeps * d->C * kRecStride * sizeof(float), 256);
 }
 size_t tab_bytes() { return align_up(sizeof(SweepTab), 256); }
-size_t flag_bytes(const PdeAdiDesc* d) { return align_up((size_t)d->C * sizeof(int), 256); }
+size_t flag_bytes(const PdeAdiDesc* d) {       // flags [C] | differs partials [S][C] | maxima partials [S][C]
+    return align_up(((size_t)flag_ints(d->C) + 2 * (size_t)d->num_sweeps * d->C) * sizeof(int), 256);
+}
 
 
 // Workgroups per channel: just enough groups to fill the chip once (measured: more groups per channel
@@ -477,6 +531,7 @@ int launch_factor(const PdeAdiDesc* d, const float* ab, const float* bb, const f
 #undef PDE_CASE
         default: return PDE_E_UNSUPPORTED_N;
     }
+    if (varying) hipLaunchKernelGGL(adi_flags_kernel, dim3(d->num_sweeps + d->C), dim3(64), 0, st, varying, kmax, d->num_sweeps, d->C);
     return check_launch();
 }
 
@@ -716,7 +771,6 @@ int pde_adi_forward(const PdeAdiDesc* d, const void* u, void* y, const float* al
     float* coef = static_cast<float*>(workspace);
     SweepTab* tab = reinterpret_cast<SweepTab*>(static_cast<char*>(workspace) + coef_bytes(d));
     int* varying = reinterpret_cast<int*>(static_cast<char*>(workspace) + coef_bytes(d) + tab_bytes());
-    hipLaunchKernelGGL(adi_zero_kernel, dim3(1), dim3(256), 0, st, varying, d->C, kappa_max, d->num_sweeps);
     rc = launch_factor(d, alpha_base, beta_base, alpha_slope, beta_slope, coef, tab, varying, kappa_max, st);
     if (rc != PDE_OK) return rc;
     rc = publish_kmax(kappa_max, kappa_max_host, kappa_event, d->num_sweeps, st);
@@ -755,7 +809,6 @@ int pde_adi_backward(const PdeAdiDesc* d, const void* gy, const void* y, const v
         tab = reinterpret_cast<SweepTab*>(const_cast<char*>(fw + coef_bytes(d)));
         varying = reinterpret_cast<int*>(const_cast<char*>(fw + coef_bytes(d) + tab_bytes()));
     } else {
-        hipLaunchKernelGGL(adi_zero_kernel, dim3(1), dim3(256), 0, st, varying, d->C, (float*)nullptr, 0);
         rc = launch_factor(d, alpha_base, beta_base, alpha_slope, beta_slope, coef, tab, varying, nullptr, st);
         if (rc != PDE_OK) return rc;
     }
@@ -788,7 +841,6 @@ int pde_adi_factor_steps(const PdeAdiDesc* d, int32_t sweeps_per_step, const flo
     float* coef = reinterpret_cast<float*>(ws);
     int* varying = reinterpret_cast<int*>(ws + coef_bytes(d));
     SweepTab* tabs = reinterpret_cast<SweepTab*>(ws + steps_tab_offset(d));
-    hipLaunchKernelGGL(adi_zero_kernel, dim3(1), dim3(256), 0, st, varying, d->C, kappa_max, d->num_sweeps);
     return launch_factor(d, alpha_base, beta_base, alpha_slope, beta_slope, coef, tabs, varying, kappa_max, st,
                          sweeps_per_step);
 }
