@@ -300,7 +300,7 @@ __global__ __launch_bounds__(128) void adi_factor_kernel(FactorArgs a) {
 // second stage of the flags / maxima: one wave per sweep (kmax[s] = max over the channels), then one per channel
 // (varying[c] = OR over the sweeps): a few parallel loads and a wave reduction each — a single workgroup walking the
 // partials serially took 14 us
-__global__ __launch_bounds__(64) void adi_flags_kernel(int* varying, float* kmax, int S, int C) {
+__global__ __launch_bounds__(64) void adi_flags_kernel(int* varying, float* kmax, float* kmax_mapped, int S, int C) {
     const int* dpart = varying + flag_ints(C);
     const float* kpart = reinterpret_cast<const float*>(dpart + (size_t)S * C);
     const int lane = threadIdx.x, b = blockIdx.x;
@@ -309,7 +309,10 @@ __global__ __launch_bounds__(64) void adi_flags_kernel(int* varying, float* kmax
         float m = 0.f;
         for (int c = lane; c < C; c += 64) m = fmaxf(m, kpart[(size_t)b * C + c]);
         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-        if (lane == 0) kmax[b] = m;
+        if (lane == 0) {
+            kmax[b] = m;
+            if (kmax_mapped) kmax_mapped[b] = m;    // the caller's pinned host buffer, written from here: no copy launch
+        }
     } else {
         const int c = b - S;
         int f = 0;
@@ -518,8 +521,17 @@ void fill_factor_args(FactorArgs& fa, const PdeAdiDesc* d, const float* ab, cons
     }
 }
 
+// device address of a pinned host buffer (hipHostMalloc memory is mapped into the device's address space); null when
+// the buffer is not mapped: the caller then copies
+float* mapped_host(float* host) {
+    void* dp = nullptr;
+    if (!host || hipHostGetDevicePointer(&dp, host, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return static_cast<float*>(dp);
+}
+
 int launch_factor(const PdeAdiDesc* d, const float* ab, const float* bb, const float* as, const float* bs,
-                  float* coef, SweepTab* tab, int* varying, float* kmax, hipStream_t st, int window = 0) {
+                  float* coef, SweepTab* tab, int* varying, float* kmax, hipStream_t st, int window = 0,
+                  float* kmax_mapped = nullptr) {
     FactorArgs fa;
     fill_factor_args(fa, d, ab, bb, as, bs);
     fa.coef = coef; fa.tab = tab; fa.varying = varying; fa.kmax = kmax;
@@ -531,7 +543,7 @@ int launch_factor(const PdeAdiDesc* d, const float* ab, const float* bb, const f
 #undef PDE_CASE
         default: return PDE_E_UNSUPPORTED_N;
     }
-    if (varying) hipLaunchKernelGGL(adi_flags_kernel, dim3(d->num_sweeps + d->C), dim3(64), 0, st, varying, kmax, d->num_sweeps, d->C);
+    if (varying) hipLaunchKernelGGL(adi_flags_kernel, dim3(d->num_sweeps + d->C), dim3(64), 0, st, varying, kmax, kmax_mapped, d->num_sweeps, d->C);
     return check_launch();
 }
 
@@ -547,8 +559,8 @@ std::mutex& launch_mutex() {
 
 // The per-sweep coefficient maxima leave for the host right behind the factor kernel, BEFORE the sweep
 // launches: whoever plans checkpoints from them waits for microseconds, not for the layer's forward.
-int publish_kmax(const float* kmax_dev, float* kmax_host, void* event, int n, hipStream_t st) {
-    if (kmax_host) {
+int publish_kmax(const float* kmax_dev, float* kmax_host, void* event, int n, hipStream_t st, bool written = false) {
+    if (kmax_host && !written) {
         if (!kmax_dev) return PDE_E_BADARG;
         if (hipMemcpyAsync(kmax_host, kmax_dev, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess)
             return PDE_E_LAUNCH;
@@ -771,9 +783,10 @@ int pde_adi_forward(const PdeAdiDesc* d, const void* u, void* y, const float* al
     float* coef = static_cast<float*>(workspace);
     SweepTab* tab = reinterpret_cast<SweepTab*>(static_cast<char*>(workspace) + coef_bytes(d));
     int* varying = reinterpret_cast<int*>(static_cast<char*>(workspace) + coef_bytes(d) + tab_bytes());
-    rc = launch_factor(d, alpha_base, beta_base, alpha_slope, beta_slope, coef, tab, varying, kappa_max, st);
+    float* km = (kappa_max && kappa_max_host) ? mapped_host(kappa_max_host) : nullptr;
+    rc = launch_factor(d, alpha_base, beta_base, alpha_slope, beta_slope, coef, tab, varying, kappa_max, st, 0, km);
     if (rc != PDE_OK) return rc;
-    rc = publish_kmax(kappa_max, kappa_max_host, kappa_event, d->num_sweeps, st);
+    rc = publish_kmax(kappa_max, kappa_max_host, kappa_event, d->num_sweeps, st, km != nullptr);
     if (rc != PDE_OK) return rc;
     return launch_fwd_sweeps(d, u, y, coef, tab, st);
 }
@@ -827,9 +840,12 @@ size_t pde_adi_steps_workspace_bytes(const PdeAdiDesc* d, int32_t sweeps_per_ste
     return steps_tab_offset(d) + align_up((size_t)(d->num_sweeps / sweeps_per_step) * sizeof(SweepTab), 256);
 }
 
-int pde_adi_factor_steps(const PdeAdiDesc* d, int32_t sweeps_per_step, const float* alpha_base, const float* beta_base,
-                         const float* alpha_slope, const float* beta_slope, float* kappa_max, void* steps_workspace,
-                         size_t workspace_bytes, void* stream) {
+// zero + factorise every sweep into a steps workspace; the per-sweep maxima optionally also straight into the caller's
+// pinned host buffer (returns through `wrote_host` whether that happened)
+static int factor_steps_impl(const PdeAdiDesc* d, int32_t sweeps_per_step, const float* alpha_base, const float* beta_base,
+                             const float* alpha_slope, const float* beta_slope, float* kappa_max, float* kappa_max_host,
+                             bool* wrote_host, void* steps_workspace, size_t workspace_bytes, void* stream) {
+    if (wrote_host) *wrote_host = false;
     int rc = check_desc(d);
     if (rc != PDE_OK) return rc;
     if (!alpha_base || !beta_base || !alpha_slope || !beta_slope || !steps_workspace) return PDE_E_BADARG;
@@ -841,8 +857,17 @@ int pde_adi_factor_steps(const PdeAdiDesc* d, int32_t sweeps_per_step, const flo
     float* coef = reinterpret_cast<float*>(ws);
     int* varying = reinterpret_cast<int*>(ws + coef_bytes(d));
     SweepTab* tabs = reinterpret_cast<SweepTab*>(ws + steps_tab_offset(d));
+    float* km = (kappa_max && kappa_max_host) ? mapped_host(kappa_max_host) : nullptr;
+    if (wrote_host) *wrote_host = km != nullptr;
     return launch_factor(d, alpha_base, beta_base, alpha_slope, beta_slope, coef, tabs, varying, kappa_max, st,
-                         sweeps_per_step);
+                         sweeps_per_step, km);
+}
+
+int pde_adi_factor_steps(const PdeAdiDesc* d, int32_t sweeps_per_step, const float* alpha_base, const float* beta_base,
+                         const float* alpha_slope, const float* beta_slope, float* kappa_max, void* steps_workspace,
+                         size_t workspace_bytes, void* stream) {
+    return factor_steps_impl(d, sweeps_per_step, alpha_base, beta_base, alpha_slope, beta_slope, kappa_max, nullptr, nullptr,
+                             steps_workspace, workspace_bytes, stream);
 }
 
 int pde_adi_forward_step(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t step, const void* u, void* y,
@@ -921,10 +946,11 @@ int pde_adi_mixed_forward(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t 
                           const float* beta_slope, float* kappa_max, float* kappa_max_host, void* kappa_event,
                           void* steps_workspace, size_t workspace_bytes, void* stream) {
     if (!u || !states || !M || (mode != 1 && mode != 2)) return PDE_E_BADARG;
-    int rc = pde_adi_factor_steps(d, sweeps_per_step, alpha_base, beta_base, alpha_slope, beta_slope, kappa_max,
-                                  steps_workspace, workspace_bytes, stream);
+    bool wrote = false;
+    int rc = factor_steps_impl(d, sweeps_per_step, alpha_base, beta_base, alpha_slope, beta_slope, kappa_max, kappa_max_host,
+                               &wrote, steps_workspace, workspace_bytes, stream);
     if (rc != PDE_OK) return rc;
-    rc = publish_kmax(kappa_max, kappa_max_host, kappa_event, d->num_sweeps, static_cast<hipStream_t>(stream));
+    rc = publish_kmax(kappa_max, kappa_max_host, kappa_event, d->num_sweeps, static_cast<hipStream_t>(stream), wrote);
     if (rc != PDE_OK) return rc;
     const int K = d->num_sweeps / sweeps_per_step, HW = d->N * d->N;
     const size_t sb = state_bytes(d);
@@ -1083,10 +1109,11 @@ int pde_adi_multi_forward(int32_t num_layers, const PdeSmallLayer* layers, const
     sa.u = u; sa.out = out; sa.B = d0->B; sa.C = d0->C; sa.L = num_layers;
     for (int i = 0; i < num_layers; ++i) {
         const PdeSmallLayer& y = layers[i];
-        rc = pde_adi_factor_steps(y.desc, y.sweeps_per_step, y.alpha_base, y.beta_base, y.alpha_slope, y.beta_slope,
-                                  y.kappa_max, y.steps_workspace, y.steps_workspace_bytes, stream);
+        bool wrote = false;
+        rc = factor_steps_impl(y.desc, y.sweeps_per_step, y.alpha_base, y.beta_base, y.alpha_slope, y.beta_slope,
+                               y.kappa_max, y.kappa_max_host, &wrote, y.steps_workspace, y.steps_workspace_bytes, stream);
         if (rc != PDE_OK) return rc;
-        rc = publish_kmax(y.kappa_max, y.kappa_max_host, nullptr, y.desc->num_sweeps, st);
+        rc = publish_kmax(y.kappa_max, y.kappa_max_host, nullptr, y.desc->num_sweeps, st, wrote);
         if (rc != PDE_OK) return rc;
         small_fill(sa.layer[i], y.desc, y.sweeps_per_step, y.mode, y.steps_workspace, y.M, y.skip_weight, y.weight, y.weight_ptr);
         sa.layer[i].states = y.states;

@@ -75,8 +75,9 @@ size_t pde_adi_backward_workspace_bytes(const PdeAdiDesc* d, int32_t num_checkpo
  * alpha_xxx / beta_xxx: (C,N,N) fp32.  u, y: (B,C,N,N) of io_dtype; y must not alias u.
  * kappa_max: NULL, or a device buffer of num_sweeps floats that receives the maximum
  * coefficient of every sweep (same values as pde_adi_kappa_max, at no extra launch).
- * kappa_max_host: NULL, or PINNED host memory of num_sweeps floats: the maxima are copied there
- * asynchronously right behind the factorisation kernel, i.e. BEFORE the sweep kernel is launched
+ * kappa_max_host: NULL, or PINNED host memory of num_sweeps floats: the maxima are written there by the
+ * factorisation's own second kernel when the buffer is mapped into the device's address space
+ * (hipHostMalloc memory is), else copied asynchronously — either way BEFORE the sweep kernel is launched
  * (needs kappa_max).  kappa_event: NULL, or a hipEvent_t the call records on `stream` behind that copy:
  * the host can plan the backward's checkpoints from this call's own coefficients after a wait of
  * microseconds, long before the forward has finished.
