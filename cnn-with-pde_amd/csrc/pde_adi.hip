@@ -1144,7 +1144,7 @@ int pde_adi_multi_backward(int32_t num_layers, const PdeSmallLayer* layers, cons
     bool any_ck = false;
     for (int i = 0; i < num_layers; ++i) {
         const PdeSmallLayer& y = layers[i];
-        if (!y.states || !y.gM || !y.workspace || (!gy && !y.gys && !y.g_plane_sums) || !y.g_alpha_base || !y.g_beta_base || !y.g_alpha_slope ||
+        if (!y.states || !y.gM || !y.workspace || !y.g_alpha_base || !y.g_beta_base || !y.g_alpha_slope ||
             !y.g_beta_slope || (y.skip_weight && !y.g_skip_weight))
             return PDE_E_BADARG;
         PdeAdiDesc ds;
@@ -1258,6 +1258,6 @@ int pde_timing_read(double* fwd_ms_sum, int64_t* fwd_launches, double* bwd_ms_su
     return PDE_OK;
 }
 
-const char* pde_version(void) { return "pdecnn-hip 0.2 (gfx950)"; }
+const char* pde_version(void) { return "pdecnn-hip 0.3 (gfx950)"; }
 
 }  // extern "C"

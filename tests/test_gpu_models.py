@@ -163,6 +163,57 @@ def test_shared_input_weighted_sum_vs_oracle(kind):
         assert G.rel_err(ys[i].detach().cpu(), O.adi_forward(u, {k: v.detach() for k, v in pr[i].items()}, specs[i])) <= TOL
 
 
+def test_shared_input_edge_cases():
+    """Four layers in one launch; bf16 tensors; fashion-size coefficients (the launch re-runs the forward to park
+    states inside the steps of the layers that need it); a loss that uses only ONE of the outputs (the other layers get
+    no incoming gradient: zero parameter gradients, no error)."""
+    import cnn_with_pde_amd as P
+    g = torch.Generator().manual_seed(23)
+    N, C, B = 28, 2, 3
+    cfg = [(0.02, 2, 1.0, 1.0), (0.3, 3, 1.0, 1.8), (0.05, 1, 2.0, 1.0), (0.1, 4, 1.5, 0.7)]     # dt, steps, dx, coefficient scale
+    layers = [quiet(P.EnhancedDiffusionLayer, N, C, dt=dt, num_steps=st, dx=dx, dy=dx) for dt, st, dx, _ in cfg]
+    specs = [O.cifar10_spec(N, C, dt=dt, dx=dx, dy=dx, num_steps=st) for dt, st, dx, _ in cfg]
+    with torch.no_grad():
+        for ly, (_, _, _, sc) in zip(layers, cfg):
+            ly.alpha_base.mul_(sc * (1 + 0.2 * torch.randn(C, N, N, generator=g)))
+            ly.beta_base.mul_(sc * (1 + 0.2 * torch.randn(C, N, N, generator=g)))
+            ly.alpha_time_coeff.copy_(0.2 * torch.randn(C, N, N, generator=g))
+            ly.channel_mixing.copy_(torch.eye(C) + 0.1 * torch.randn(C, C, generator=g))
+    w = torch.softmax(torch.randn(4, generator=g), 0)
+    u = torch.randn(B, C, N, N, generator=g)
+    gy = torch.randn(B, C, N, N, generator=g)
+    ur = u.clone().requires_grad_(True)
+    pr = [{k: v.detach().clone().requires_grad_(True) for k, v in ly.named_parameters()} for ly in layers]
+    ref = sum(w[i] * O.adi_forward(ur, pr[i], specs[i]) for i in range(4))
+    ref.backward(gy)
+    layers = [ly.cuda() for ly in layers]
+    ud = u.cuda().requires_grad_(True)
+    out, ys = P.diffuse_shared_input(layers, ud, w.cuda())
+    out.backward(gy.cuda())
+    assert G.rel_err(out.detach().cpu(), ref.detach()) <= TOL and G.rel_err(ud.grad.cpu(), ur.grad) <= TOL
+    for i, ly in enumerate(layers):
+        for n, p in ly.named_parameters():
+            assert G.rel_err(p.grad.cpu(), pr[i][n].grad) <= TOL, (i, n)
+    # only y_2 enters the loss
+    for ly in layers:
+        for p in ly.parameters():
+            p.grad = None
+    u2 = u.cuda().requires_grad_(True)
+    _, ys = P.diffuse_shared_input(layers, u2)
+    ys[1].backward(gy.cuda())
+    ur2 = u.clone().requires_grad_(True)
+    O.adi_forward(ur2, pr[1], specs[1]).backward(gy)
+    assert G.rel_err(u2.grad.cpu(), ur2.grad) <= TOL
+    assert all(float(p.grad.abs().max()) == 0.0 for i in (0, 2, 3) for p in layers[i].parameters())
+    # bf16 tensors through two layers and the weighted sum
+    ub = u.bfloat16().cuda().requires_grad_(True)
+    ob, _ = P.diffuse_shared_input(layers[:2], ub, w[:2].cuda())
+    assert ob.dtype == torch.bfloat16
+    ob.backward(gy.bfloat16().cuda())
+    ref2 = sum(w[i] * O.adi_forward(u.bfloat16().float(), {k: v.detach() for k, v in pr[i].items()}, specs[i]) for i in range(2))
+    assert G.rel_err(ob.detach().float().cpu(), ref2) <= 2e-2
+
+
 def _fit(model, x, target, steps, lr, amp=False, params=None):
     """``steps`` optimiser steps on one fixed batch, as the reference trains (AdamW + clip_grad_norm 1.0,
     mnist_test.py:282-306; under fp16 autocast with a GradScaler as cifar10.py:440,458-467 when ``amp``)."""
