@@ -524,8 +524,17 @@ void fill_factor_args(FactorArgs& fa, const PdeAdiDesc* d, const float* ab, cons
 // device address of a pinned host buffer (hipHostMalloc memory is mapped into the device's address space); null when
 // the buffer is not mapped: the caller then copies
 float* mapped_host(float* host) {
+    // Used on single-GPU processes' hosts only (one visible device), where it is measured; with several devices visible
+    // the copy path is kept unless PDE_KMAX_MAPPED=1 (a kernel store into memory another device's driver state mapped
+    // is not something this build could test).
+    static const int allow = [] {
+        const int e = env_int("PDE_KMAX_MAPPED", -1);
+        if (e >= 0) return e;
+        int n = 0;
+        return (hipGetDeviceCount(&n) == hipSuccess && n == 1) ? 1 : 0;
+    }();
     void* dp = nullptr;
-    if (!host || hipHostGetDevicePointer(&dp, host, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (!allow || !host || hipHostGetDevicePointer(&dp, host, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     return static_cast<float*>(dp);
 }
 

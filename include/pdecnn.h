@@ -76,8 +76,8 @@ size_t pde_adi_backward_workspace_bytes(const PdeAdiDesc* d, int32_t num_checkpo
  * kappa_max: NULL, or a device buffer of num_sweeps floats that receives the maximum
  * coefficient of every sweep (same values as pde_adi_kappa_max, at no extra launch).
  * kappa_max_host: NULL, or PINNED host memory of num_sweeps floats: the maxima are written there by the
- * factorisation's own second kernel when the buffer is mapped into the device's address space
- * (hipHostMalloc memory is), else copied asynchronously — either way BEFORE the sweep kernel is launched
+ * factorisation's own second kernel when the buffer is mapped into the device's address space and the
+ * process sees one device, else copied asynchronously — either way BEFORE the sweep kernel is launched
  * (needs kappa_max).  kappa_event: NULL, or a hipEvent_t the call records on `stream` behind that copy:
  * the host can plan the backward's checkpoints from this call's own coefficients after a wait of
  * microseconds, long before the forward has finished.
