@@ -483,7 +483,7 @@ class _AdiMultiFn(torch.autograd.Function):
     Returns (sum_i w_i y_i, y_1, ..., y_L); the y_i are the last sweep outputs the kernel keeps anyway."""
 
     @staticmethod
-    def forward(ctx, u, weights, specs, want_sums, *flat):
+    def forward(ctx, u, weights, specs, want_sums, ckpt, *flat):
         lib = L.load()
         nl = len(specs)
         _require_cuda(u, weights, *flat)
@@ -492,6 +492,8 @@ class _AdiMultiFn(torch.autograd.Function):
             u = u.float()
         u = u.contiguous()
         need_grad = any(ctx.needs_input_grad)
+        want_kmax = need_grad and ckpt == "auto"
+        ctx.ckpt = ckpt
         ctx.set_materialize_grads(False)
         wdev = None if weights is None else weights.detach().to(torch.float32).contiguous()   # read by the kernels on the device
         arr = (L.PdeSmallLayer * nl)()
@@ -505,9 +507,9 @@ class _AdiMultiFn(torch.autograd.Function):
             d = _make_desc(B, Cc, N, _io_dtype(u), sweeps, smooth3, clamp_max, eps)
             sws = _workspace(lib.pde_adi_steps_workspace_bytes(C.byref(d), sps), u.device)
             states = torch.empty((K,) + tuple(u.shape), dtype=u.dtype, device=u.device)
-            kdev = torch.empty(len(sweeps), dtype=torch.float32, device=u.device) if need_grad else None
+            kdev = torch.empty(len(sweeps), dtype=torch.float32, device=u.device) if want_kmax else None
             with torch.cuda.device(u.device):
-                tk = _kmax_channel(len(sweeps)) if need_grad else None
+                tk = _kmax_channel(len(sweeps)) if want_kmax else None
             host = tk.host if tk else None
             a = arr[i]
             a.desc, a.sweeps_per_step, a.mode = C.pointer(d), sps, 1
@@ -527,7 +529,7 @@ class _AdiMultiFn(torch.autograd.Function):
             per.append((sps, K, [t.shape for t in (ab, bb, asl, bsl)], M.dtype))
         out = torch.empty_like(u)
         with torch.cuda.device(u.device):
-            ev = keep[-1][5].event if need_grad else None      # recorded behind the last layer's copy
+            ev = keep[-1][5].event if want_kmax else None      # recorded behind the last layer's copy
             L.check(lib.pde_adi_multi_forward(nl, arr, _ptr(u), _ptr(out), C.c_void_p(ev.cuda_event if ev is not None else 0),
                                               _stream()), "pde_adi_multi_forward")
         ctx.keep, ctx.descs, ctx.per, ctx.u, ctx.wdev = keep, descs, per, u, wdev
@@ -544,17 +546,21 @@ class _AdiMultiFn(torch.autograd.Function):
         u = ctx.u
         B, Cc, N, _ = u.shape
         arr = (L.PdeSmallLayer * nl)()
-        ctx.keep[-1][5].event.synchronize()
+        if ctx.ckpt == "auto":
+            ctx.keep[-1][5].event.synchronize()
         outs, hold = [], []
         gout_c = None if gout is None else gout.to(u.dtype).contiguous()
         for i in range(nl):
             p, Mf, sws, states, kdev, tk = ctx.keep[i]
             sps, K, shapes, Mdt = ctx.per[i]
             d = ctx.descs[i]
-            km = tk.host.tolist()
             bits = 0
-            for k in range(K):
-                bits |= plan_checkpoints(km[k * sps:(k + 1) * sps])
+            if ctx.ckpt == "auto":
+                km = tk.host.tolist()
+                for k in range(K):
+                    bits |= plan_checkpoints(km[k * sps:(k + 1) * sps])
+            else:
+                bits = int(ctx.ckpt)
             mask = (C.c_uint64 * 2)(bits & (2 ** 64 - 1), bits >> 64)
             ws = _workspace(lib.pde_adi_small_backward_workspace_bytes(C.byref(d), sps, bin(bits).count("1")), u.device)
             gp = [torch.empty_like(t) for t in p]
@@ -587,23 +593,24 @@ class _AdiMultiFn(torch.autograd.Function):
         for gp, gM, gw, shapes, Mdt in outs:
             flat += [g.reshape(s) for g, s in zip(gp, shapes)] + [gM.to(Mdt)]
         gweights = torch.cat([o[2] for o in outs]) if ctx.has_w else None
-        return (gu, gweights, None, None, *flat)
+        return (gu, gweights, None, None, None, *flat)
 
 
-def adi_diffuse_multi(u, layers, weights=None, plane_sums=False):
+def adi_diffuse_multi(u, layers, weights=None, plane_sums=False, checkpoints="auto"):
     """Run several mixing-first layers on the same ``u`` in one launch per pass.
 
     ``layers``: list of dicts with keys alpha_base, beta_base, alpha_time_coeff, beta_time_coeff, M, steps and
     optionally smooth3, clamp_max, eps.  ``weights`` (L,): ``out = sum_i weights[i] * y_i`` (cifar10.py:277-280
     without the attention gates); None: ``out`` is not meaningful.  Returns ``(out, [y_1 .. y_L])``, and with
     ``plane_sums`` also ``[s_1 .. s_L]``, ``s_i[b,c] = sum_hw y_i`` — the adaptive average pool of
-    cifar10.py:239 times H*W, a by-product of the kernel (differentiable like the ``y_i``)."""
+    cifar10.py:239 times H*W, a by-product of the kernel (differentiable like the ``y_i``).  ``checkpoints``: "auto"
+    or one step-local bit mask for every layer (an int: no host wait at all — the call is then hipGraph-capturable)."""
     specs = tuple((_as_schedule(ly["steps"]), bool(ly.get("smooth3", False)), ly.get("clamp_max"),
                    float(ly.get("eps", 1e-6))) for ly in layers)
     flat = []
     for ly in layers:
         flat += [ly["alpha_base"], ly["beta_base"], ly["alpha_time_coeff"], ly["beta_time_coeff"], ly["M"]]
-    res = _AdiMultiFn.apply(u, weights, specs, bool(plane_sums), *flat)
+    res = _AdiMultiFn.apply(u, weights, specs, bool(plane_sums), checkpoints, *flat)
     nl = len(layers)
     if plane_sums:
         return res[0], list(res[1:1 + nl]), list(res[1 + nl:])
