@@ -40,6 +40,7 @@
 //     written as one value (Pack<J>) so that the packed form stays one flag away (make PACK=1: 4 % slower).
 #include "pde_adi_dev.h"
 #include "pde_adi_small.h"
+#include "pde_adi_wide.h"
 #include "pde_adi_launch.h"
 
 #include <cmath>
@@ -82,6 +83,7 @@ struct FactorArgs {
     const float* as;
     const float* bs;
     float* coef;            // [S][C][kRecAll]
+    float* wide;            // optional [S][C][kWideRec]: lane-major copy of the records (pde_common.h), may be null
     float* kmax;            // optional [S] (atomic max of coeff), may be null
     int C, N, S;
     int win;                // sweeps per launch window: tab[w] describes sweeps w*win .. w*win+win-1 as ONE launch
@@ -280,6 +282,24 @@ __global__ __launch_bounds__(128) void adi_factor_kernel(FactorArgs a) {
         }
         store_half_row<N>(row + kG_KapX, hf, idle ? zero : kx);
         store_half_row<N>(row + kG_MaskX, hf, idle ? zero : mx);
+        if (a.wide != nullptr) {                     // lane-major copy, straight from my registers
+            float* wr = a.wide + ((size_t)s * a.C + c) * kWideRec;
+            const int wl = threadIdx.x & 63;
+            if (hf == 0) wr[kW_Jn + line] = idle ? 0.f : 1.0f / (1.0f - e_lo * e_hi);
+            auto put = [&](int off, const float (&v)[m]) __attribute__((always_inline)) {
+                float4* dst = reinterpret_cast<float4*>(wr + off) + wl;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4 x;
+                    x.x = (4 * q < m && !idle) ? v[4 * q < m ? 4 * q : 0] : 0.f;
+                    x.y = (4 * q + 1 < m && !idle) ? v[4 * q + 1 < m ? 4 * q + 1 : 0] : 0.f;
+                    x.z = (4 * q + 2 < m && !idle) ? v[4 * q + 2 < m ? 4 * q + 2 : 0] : 0.f;
+                    x.w = (4 * q + 3 < m && !idle) ? v[4 * q + 3 < m ? 4 * q + 3 : 0] : 0.f;
+                    dst[q * 64] = x;
+                }
+            };
+            put(kW_Inv, inv); put(kW_E, ee); put(kW_InvB, invb); put(kW_KapX, kx);
+        }
         __builtin_amdgcn_wave_barrier();
         static_assert(kRecStride % 4 == 0, "record is a whole number of 16-byte pieces");
         const float4* src = reinterpret_cast<const float4*>(rec);
@@ -508,7 +528,7 @@ int groups_per_channel(const PdeAdiDesc* d, int planes_per_iter, int wg_per_cu) 
 
 void fill_factor_args(FactorArgs& fa, const PdeAdiDesc* d, const float* ab, const float* bb, const float* as,
                       const float* bs) {
-    fa.tab = nullptr; fa.varying = nullptr; fa.coef = nullptr; fa.kmax = nullptr;
+    fa.tab = nullptr; fa.varying = nullptr; fa.coef = nullptr; fa.kmax = nullptr; fa.wide = nullptr;
     fa.ab = ab; fa.bb = bb; fa.as = as; fa.bs = bs;
     fa.C = d->C; fa.N = d->N; fa.S = d->num_sweeps; fa.win = d->num_sweeps;
     fa.smooth3 = d->smooth3; fa.has_max = d->has_clamp_max; fa.cmax = d->clamp_max; fa.eps = d->eps;
@@ -540,10 +560,10 @@ float* mapped_host(float* host) {
 
 int launch_factor(const PdeAdiDesc* d, const float* ab, const float* bb, const float* as, const float* bs,
                   float* coef, SweepTab* tab, int* varying, float* kmax, hipStream_t st, int window = 0,
-                  float* kmax_mapped = nullptr) {
+                  float* kmax_mapped = nullptr, float* wide = nullptr) {
     FactorArgs fa;
     fill_factor_args(fa, d, ab, bb, as, bs);
-    fa.coef = coef; fa.tab = tab; fa.varying = varying; fa.kmax = kmax;
+    fa.coef = coef; fa.tab = tab; fa.varying = varying; fa.kmax = kmax; fa.wide = wide;
     if (window > 0) fa.win = window;
     const dim3 grid(d->num_sweeps * ((d->C + 1) / 2));
     switch (d->N) {
@@ -759,6 +779,11 @@ int step_desc(const PdeAdiDesc* d, int sps, int k, PdeAdiDesc& ds) {
 }
 // layout of the whole-schedule ("steps") workspace: records of all sweeps | channel flags | one table per step
 size_t steps_tab_offset(const PdeAdiDesc* d) { return coef_bytes(d) + flag_bytes(d); }
+// ... | lane-major records (only where the one-launch C = 32 / 64 path applies)
+size_t steps_wide_offset(const PdeAdiDesc* d, int sps) {
+    return steps_tab_offset(d) + align_up((size_t)(d->num_sweeps / sps) * sizeof(SweepTab), 256);
+}
+bool wide_supported(const PdeAdiDesc* d, int sps);
 
 }  // namespace
 }  // namespace pde
@@ -846,7 +871,8 @@ int pde_adi_backward(const PdeAdiDesc* d, const void* gy, const void* y, const v
 // ---- one layer call as a sequence of per-step launches (layers with a channel operator between the steps) ----
 size_t pde_adi_steps_workspace_bytes(const PdeAdiDesc* d, int32_t sweeps_per_step) {
     if (check_desc(d) != PDE_OK || sweeps_per_step <= 0 || d->num_sweeps % sweeps_per_step) return 0;
-    return steps_tab_offset(d) + align_up((size_t)(d->num_sweeps / sweeps_per_step) * sizeof(SweepTab), 256);
+    return steps_wide_offset(d, sweeps_per_step) +
+           (wide_supported(d, sweeps_per_step) ? align_up((size_t)d->num_sweeps * d->C * kWideRec * sizeof(float), 256) : 0);
 }
 
 // zero + factorise every sweep into a steps workspace; the per-sweep maxima optionally also straight into the caller's
@@ -868,8 +894,9 @@ static int factor_steps_impl(const PdeAdiDesc* d, int32_t sweeps_per_step, const
     SweepTab* tabs = reinterpret_cast<SweepTab*>(ws + steps_tab_offset(d));
     float* km = (kappa_max && kappa_max_host) ? mapped_host(kappa_max_host) : nullptr;
     if (wrote_host) *wrote_host = km != nullptr;
+    float* wide = wide_supported(d, sweeps_per_step) ? reinterpret_cast<float*>(ws + steps_wide_offset(d, sweeps_per_step)) : nullptr;
     return launch_factor(d, alpha_base, beta_base, alpha_slope, beta_slope, coef, tabs, varying, kappa_max, st,
-                         sweeps_per_step, km);
+                         sweeps_per_step, km, wide);
 }
 
 int pde_adi_factor_steps(const PdeAdiDesc* d, int32_t sweeps_per_step, const float* alpha_base, const float* beta_base,
@@ -950,6 +977,43 @@ static size_t state_bytes(const PdeAdiDesc* d) {
     return (size_t)d->B * d->C * d->N * d->N * (d->io_dtype == PDE_IO_BF16 ? 2 : 4);
 }
 
+// ---- C = 32 / 64 fp32: the whole forward in one launch (pde_adi_wide.h) ----
+static int small_split(const PdeAdiDesc* d, int sps);
+namespace pde { namespace {
+static bool wide_enabled() {
+    static const bool on = [] { const char* e = getenv("PDE_WIDE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+bool wide_supported(const PdeAdiDesc* d, int sps) {
+    if (!wide_enabled() || d->io_dtype != PDE_IO_F32 || (d->C != 32 && d->C != 64)) return false;
+    bool n_ok = false;
+#define PDE_WIDE_CASE(NN) n_ok |= (d->N == NN);
+    PDE_WIDE_N_LIST
+#undef PDE_WIDE_CASE
+    if (!n_ok || (sps != 2 && sps != 3) || d->num_sweeps % sps) return false;
+    const int sp = small_split(d, sps);
+    return (sp == kSplitStrang && sps == 3) || (sp == kSplitLie && sps == 2);
+}
+} }
+static int wide_forward(const PdeAdiDesc* d, int sps, int mode, const void* u, void* states, const float* M,
+                        const void* steps_workspace, int keep, hipStream_t st) {
+    WideArgs wa{};
+    wa.u = u; wa.states = states; wa.M = M;
+    wa.coef = reinterpret_cast<const float*>(static_cast<const char*>(steps_workspace) + steps_wide_offset(d, sps));
+    wa.B = d->B; wa.K = d->num_sweeps / sps; wa.mode = mode; wa.keep = keep;
+    const int grid = d->B < 2048 ? d->B : 2048;
+    switch (d->N) {
+#define PDE_WIDE_CASE(NN) case NN: return adi_launch_wide_fwd_##NN(d->C, small_split(d, sps), &wa, grid, st);
+        PDE_WIDE_N_LIST
+#undef PDE_WIDE_CASE
+    }
+    return PDE_E_UNSUPPORTED_N;
+}
+
+int pde_adi_mixed_one_launch(const PdeAdiDesc* d, int32_t sweeps_per_step) {
+    return (check_desc(d) == PDE_OK && wide_supported(d, sweeps_per_step)) ? 1 : 0;
+}
+
 int pde_adi_mixed_forward(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t mode, const void* u, void* states,
                           const float* M, const float* alpha_base, const float* beta_base, const float* alpha_slope,
                           const float* beta_slope, float* kappa_max, float* kappa_max_host, void* kappa_event,
@@ -962,6 +1026,8 @@ int pde_adi_mixed_forward(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t 
     rc = publish_kmax(kappa_max, kappa_max_host, kappa_event, d->num_sweeps, static_cast<hipStream_t>(stream), wrote);
     if (rc != PDE_OK) return rc;
     const int K = d->num_sweeps / sweeps_per_step, HW = d->N * d->N;
+    if (wide_supported(d, sweeps_per_step))
+        return wide_forward(d, sweeps_per_step, mode, u, states, M, steps_workspace, 1, static_cast<hipStream_t>(stream));
     const size_t sb = state_bytes(d);
     char* st = static_cast<char*>(states);
     const void* cur = u;
@@ -1010,6 +1076,19 @@ int pde_adi_mixed_backward(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t
     const char* st = static_cast<const char*>(states);
     const void* g_in = gy;                                 // gradient entering the step (never written)
     int rc = PDE_OK;
+    if (nck && wide_supported(d, sweeps_per_step)) {
+        // the one-launch forward kept the sweep outputs only; a checkpointed backward also reads the operator's outputs
+        char* sw = const_cast<char*>(st);
+        for (int k = 0; k < K && rc == PDE_OK; ++k) {
+            if (mode == 1)
+                rc = pde_channel_mix_forward(d->B, d->C, HW, d->io_dtype, k ? sw + (size_t)(2 * k - 1) * sb : u, M,
+                                             sw + (size_t)(2 * k) * sb, stream);
+            else if (k + 1 < K)
+                rc = pde_channel_mix_forward(d->B, d->C, HW, d->io_dtype, sw + (size_t)(2 * k) * sb, M,
+                                             sw + (size_t)(2 * k + 1) * sb, stream);
+        }
+        if (rc != PDE_OK) return rc;
+    }
     for (int k = K - 1; k >= 0; --k) {
         const int first = (k == K - 1), last = (k == 0);
         const void* a_k = st + (size_t)(2 * k) * sb;

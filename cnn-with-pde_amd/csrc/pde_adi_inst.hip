@@ -5,6 +5,10 @@
 #define PDE_INST_SMALL 1
 #include "pde_adi_small.h"
 #endif
+#if PDE_INST_N == 28 || PDE_INST_N == 32
+#define PDE_INST_WIDE 1
+#include "pde_adi_wide.h"
+#endif
 
 #ifndef PDE_INST_N
 #error "compile with -DPDE_INST_N=<line length>"
@@ -74,6 +78,12 @@ int PDE_CAT(adi_launch_small_bwd_, PDE_INST_N)(int io, int split, const void* ar
     const SmallArgs& sa = *static_cast<const SmallArgs*>(args);
     return io == PDE_IO_F32 ? small_bwd_io<PDE_INST_N, float>(split, sa, grid, lds, st)
                             : small_bwd_io<PDE_INST_N, bf16_t>(split, sa, grid, lds, st);
+}
+#endif
+
+#ifdef PDE_INST_WIDE
+int PDE_CAT(adi_launch_wide_fwd_, PDE_INST_N)(int C, int split, const void* args, int grid, hipStream_t st) {
+    return wide_fwd_launch<PDE_INST_N>(C, split, *static_cast<const WideArgs*>(args), grid, st);
 }
 #endif
 

@@ -24,4 +24,10 @@ PDE_DECLARE_N(8) PDE_DECLARE_N(12) PDE_DECLARE_N(16) PDE_DECLARE_N(20) PDE_DECLA
     int adi_launch_small_bwd_##NN(int io, int split, const void* args, int grid, size_t lds, hipStream_t st);
 PDE_SMALL_N_LIST
 #undef PDE_SMALL_CASE
+
+// whole-layer forward for C = 32 / 64 fp32 (pde_adi_wide.h)
+#define PDE_WIDE_N_LIST PDE_WIDE_CASE(28) PDE_WIDE_CASE(32)
+#define PDE_WIDE_CASE(NN) int adi_launch_wide_fwd_##NN(int C, int split, const void* args, int grid, hipStream_t st);
+PDE_WIDE_N_LIST
+#undef PDE_WIDE_CASE
 }  // namespace pde

@@ -45,6 +45,14 @@ constexpr int kRecBwd = 3 * kImage + 32;             // JN, E, INVB, KAPX
 constexpr int kRecBwdMasked = 4 * kImage + 32;       // ... + MASKX
 constexpr int kB_Jn = 0, kB_E = 32, kB_Inv = kImage + 32, kB_KapX = 2 * kImage + 32, kB_MaskX = 3 * kImage + 32;
 
+// Lane-major copy of a record for the kernels that read coefficients straight from memory (pde_adi_wide.h): every
+// image as [4 quads][64 lanes][4 floats] — lane (line, half) finds its 16 values of an image at 4 x 16 bytes that are
+// CONTIGUOUS ACROSS LANES (a wave-level 16-byte load covers 1 KB; the [32][36] image gives 64 different cache lines).
+//   [JN 64 (32 used)][INV][E][INVB][KAPX], INV/E/INVB by the sweep's own lines, KAPX by rows, as above
+constexpr int kWideImage = 4 * 64 * 4;
+constexpr int kW_Jn = 0, kW_Inv = 64, kW_E = 64 + kWideImage, kW_InvB = 64 + 2 * kWideImage, kW_KapX = 64 + 3 * kWideImage;
+constexpr int kWideRec = 64 + 4 * kWideImage;         // 4160 floats
+
 // position of global index j inside a line image row
 __host__ __device__ inline int half_pos(int j, int N) { return (j < N / 2) ? j : kHalfPad + (N - 1 - j); }
 

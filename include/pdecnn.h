@@ -152,7 +152,14 @@ int pde_adi_param_grads(const PdeAdiDesc* d, int32_t sweeps_per_step,
  * mode 1: u <- M u before every step (cifar10.py:91, cifar_2version.py:86); 2: after every step
  * (SVHN.py:71).  `states`: K*2 tensors of u's shape and type, K = num_sweeps / sweeps_per_step —
  * states[2k] the output of step k's first operator, states[2k+1] of its second; the layer output is
- * states[2K-1].  The backward needs them intact, and `u`.  ckpt_mask is relative to a step. */
+ * states[2K-1].  The backward needs them intact, and `u`.  ckpt_mask is relative to a step.
+ * pde_adi_mixed_one_launch: 1 when the forward of (d, sweeps_per_step) runs as the factorisation plus ONE launch
+ * (fp32 tensors, C = 32 or 64, N = 28 or 32, every step x,y,x or x,y: a workgroup owns all channels of a sample for
+ * the whole time loop and mixes them with the fp32 MFMA through LDS; the environment variable PDE_WIDE=0 turns it
+ * off), else 0: one mixing launch and one sweep launch per step.  In the one-launch case the forward writes only
+ * the sweep output of every step (states[2k+1] for mode 1, states[2k] for mode 2) and states[2K-1]; the backward
+ * recomputes the other slots itself when its checkpoints need them, so the contract above is unchanged. */
+int pde_adi_mixed_one_launch(const PdeAdiDesc* d, int32_t sweeps_per_step);
 int pde_adi_mixed_forward(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t mode,
                           const void* u, void* states, const float* M,
                           const float* alpha_base, const float* beta_base,

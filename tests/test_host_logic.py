@@ -150,4 +150,4 @@ def test_counterpart_models_keep_the_reference_names():
             want += 1e-4 * float(torch.norm(p, p=2) ** 2)
         elif n.endswith("combination_weights"):
             want += 1e-4 * float(torch.norm(p, p=1))
-    assert abs(float(reg) - want) <= 1e-6 * want
+    assert abs(float(reg) - want) <= 1e-5 * want          # fp32 sums in another order (random initial weights)
