@@ -365,7 +365,9 @@ def main():
         dt2 = timed(layer2, u, gy, k2, 2, dist_on, flat2)
         if rank == 0:
             out["secondary"] = {"config": "same workload with the C x C channel mixing before every step "
-                                          "(cifar10.py:91): one factorisation, then 10 x (MFMA mix kernel + 3-sweep launch); backward with the fused mixing-gradient kernel, gradients accumulated on the device",
+                                          "(cifar10.py:91): one factorisation, the forward in ONE launch (a workgroup owns all 64 channels of a "
+                                          "sample, fp32-MFMA mixing through LDS); backward per step: 3-sweep adjoint launch + fused "
+                                          "mixing-gradient kernel, gradients accumulated on the device",
                                 "value": B * world * k2 / dt2 / 1e6, "unit": "Msamples/s",
                                 "ms_per_step": dt2 / k2 * 1e3}
         del layer2
