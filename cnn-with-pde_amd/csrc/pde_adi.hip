@@ -413,22 +413,30 @@ __global__ __launch_bounds__(1024) void adi_pgrad_kernel(PgradArgs a) {
     const int N = a.N;
     const int tid = threadIdx.x;
     if ((int)blockIdx.x == 4 * a.C) {                 // (only launched when gm_part is given)
-        if (tid < a.C * a.C) {
-            const int i = tid / a.C, j = tid % a.C;
+        // C*C matrix entries + the skip-weight term + the output-weight term: one WAVE per output, its lanes stride
+        // over the workgroups' partials and meet in a butterfly (fixed order).  One THREAD per output walking the
+        // partials one dependent load after the other took 33 us for 128 workgroups.
+        const int lane = tid & 63, wv = tid >> 6, nout = a.C * a.C + 2;
+        for (int o = wv; o < nout; o += 16) {
             float sum = 0.f;
-            for (int g = 0; g < a.gm_blocks; ++g) sum += a.gm_part[((size_t)g * a.C + i) * kGmStride + j];
-            a.gM[tid] = sum;
-        } else if (tid == a.C * a.C && a.g_skip != nullptr) {
-            float sum = 0.f;
-            for (int g = 0; g < a.gm_blocks; ++g)
-                for (int i = 0; i < a.C; ++i) sum += a.gm_part[((size_t)g * a.C + i) * kGmStride + kSmallMaxC];
-            const float sg = 1.0f / (1.0f + expf(-*a.skip_w));
-            *a.g_skip = (1.0f - sg) * sum;             // the kernel's partials already carry one factor sigmoid
-        } else if (tid == a.C * a.C + 1 && a.g_w != nullptr) {
-            float sum = 0.f;
-            for (int g = 0; g < a.gm_blocks; ++g)
-                for (int i = 0; i < a.C; ++i) sum += a.gm_part[((size_t)g * a.C + i) * kGmStride + kGmStride - 1];
-            *a.g_w = sum;
+            if (o < a.C * a.C) {
+                const int i = o / a.C, j = o % a.C;
+                for (int g = lane; g < a.gm_blocks; g += 64) sum += a.gm_part[((size_t)g * a.C + i) * kGmStride + j];
+            } else {
+                const int col = (o == a.C * a.C) ? kSmallMaxC : kGmStride - 1;
+                for (int g = lane; g < a.gm_blocks; g += 64)
+                    for (int i = 0; i < a.C; ++i) sum += a.gm_part[((size_t)g * a.C + i) * kGmStride + col];
+            }
+            for (int x = 32; x > 0; x >>= 1) sum += __shfl_xor(sum, x, 64);
+            if (lane == 0) {
+                if (o < a.C * a.C) a.gM[o] = sum;
+                else if (o == a.C * a.C) {
+                    if (a.g_skip != nullptr) {
+                        const float sg = 1.0f / (1.0f + expf(-*a.skip_w));
+                        *a.g_skip = (1.0f - sg) * sum;     // the kernel's partials already carry one factor sigmoid
+                    }
+                } else if (a.g_w != nullptr) *a.g_w = sum;
+            }
         }
         return;
     }
