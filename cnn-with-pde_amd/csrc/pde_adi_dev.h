@@ -504,8 +504,9 @@ __device__ __forceinline__ void store_planes(IO* base, int q, int wave, int lane
 // ---- forward kernel ---------------------------------------------------------------------
 // SPLIT fixes the order of the axes inside a time step at compile time (straight-line code per
 // step, no per-sweep axis branch); kSplitAny reads the axis of every sweep from the table.
+// (second bound: waves per SIMD.  4 = two workgroups per CU; the bf16 instantiation otherwise takes 138 VGPRs and runs alone on its CU)
 template <int N, int J, typename IO, int SPLIT>
-__global__ __launch_bounds__(kThreads) void adi_fwd_kernel(SweepArgs a) {
+__global__ __launch_bounds__(kThreads, (sizeof(IO) < 4 ? 4 : 1)) void adi_fwd_kernel(SweepArgs a) {
     constexpr int M = Geo<N>::M;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* cbuf = smem;                                   // [kRing][kRecFwdPad]
