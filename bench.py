@@ -215,12 +215,32 @@ def config_legs(dev, rank, world, dist_on, quick):
             trio_step(fused)
         torch.cuda.synchronize()
         res[fused] = (time.perf_counter() - t0) / (3 * k) * 1e3
+    # the same step replayed from a hipGraph (cnn_with_pde_amd.graphs): explicit checkpoint plans, launches only
+    graph_ms = None
+    try:
+        for ly in trio:
+            ly.freeze_checkpoint_plan(x)
+        params = [p_ for ly in trio for p_ in ly.parameters()]
+        step = P.GraphedStep(lambda: torch.autograd.grad(P.diffuse_shared_input(trio, x, w)[0], [x, w] + params, gx))
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(6 * k):
+            step()
+        torch.cuda.synchronize()
+        graph_ms = (time.perf_counter() - t0) / (6 * k) * 1e3
+    except Exception as e:                                   # reported, never fatal for the bench line
+        graph_ms = "capture failed: %s" % (str(e)[:120],)
     if rank == 0:
         legs["cifar10_trio_c3"] = {"workload": "the three EnhancedDiffusionLayers of cifar10.MultiScaleExtractor (C=3, 5/8/4 steps) on one "
                                                "(128,3,32,32) batch + weighted sum, forward+backward (reference shapes, cifar10.py:251-280)",
                                    "ms_per_step": res[True], "ms_per_step_one_call_per_layer": res[False],
+                                   "ms_per_step_hipgraph_replay": graph_ms,
                                    "value": 128 / res[True] / 1e3, "unit": "Msamples/s",
-                                   "note": "one launch per pass for all three layers (pde_adi_multi_*); bound by the host's launch path"}
+                                   "note": "one launch per pass for all three layers (pde_adi_multi_*); the eager figures are bound by the host's "
+                                           "launch path, ms_per_step_hipgraph_replay is the same forward+backward captured once "
+                                           "(cnn_with_pde_amd.graphs.GraphedStep, checkpoint plans frozen) and replayed"}
     return legs
 
 

@@ -7,6 +7,8 @@ from .dist import shard_range, shard_batch, GradBucket
 from .layers import (MnistDiffusionLayer, FashionDiffusionLayer, SvhnDiffusionLayer, EnhancedDiffusionLayer,
                      LearnableDiffusionLayer, ImprovedDiffusionLayer, PDELayer)
 from . import models
+from . import graphs
+from .graphs import freeze_checkpoint_plans, make_graphed, GraphedStep
 from .models import (MnistPDEClassifier, FashionPDEClassifier, SvhnPDEClassifier, SpatialAttention, MultiScaleExtractor,
                      EnhancedFC, CIFAR10PDENoConv, SymmetricLayer, ParabolicBlock, HamiltonianBlock, HybridPDEExtractor,
                      NonConvSpatialAttention, HybridClassifierHead, CIFAR10HybridPDEModel, hybrid_pde_regularization,
@@ -44,7 +46,7 @@ def library_version() -> str:
     return _lib.load().pde_version().decode()
 
 
-__all__ = ["PdeError", "LIB_PATH", "Sweep", "adi_schedule", "adi_diffuse", "adi_diffuse_mixed", "adi_diffuse_small",
+__all__ = ["graphs", "freeze_checkpoint_plans", "make_graphed", "GraphedStep", "PdeError", "LIB_PATH", "Sweep", "adi_schedule", "adi_diffuse", "adi_diffuse_mixed", "adi_diffuse_small",
            "adi_diffuse_multi", "gate_combine", "plan_checkpoints", "channel_mix", "explicit5_step",
            "jacobi_diffuse", "timing_enable", "timing_read", "MnistDiffusionLayer", "FashionDiffusionLayer",
            "SvhnDiffusionLayer", "EnhancedDiffusionLayer", "LearnableDiffusionLayer", "ImprovedDiffusionLayer",

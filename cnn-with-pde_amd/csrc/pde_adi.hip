@@ -877,10 +877,13 @@ int pde_adi_backward(const PdeAdiDesc* d, const void* gy, const void* y, const v
 }
 
 // ---- one layer call as a sequence of per-step launches (layers with a channel operator between the steps) ----
+static size_t state_bytes(const PdeAdiDesc* d);
 size_t pde_adi_steps_workspace_bytes(const PdeAdiDesc* d, int32_t sweeps_per_step) {
     if (check_desc(d) != PDE_OK || sweeps_per_step <= 0 || d->num_sweeps % sweeps_per_step) return 0;
+    // ... | lane-major records (C = 32 / 64 one-launch forward)  or  this layer's term of a shared-input group's output (C <= 4)
     return steps_wide_offset(d, sweeps_per_step) +
-           (wide_supported(d, sweeps_per_step) ? align_up((size_t)d->num_sweeps * d->C * kWideRec * sizeof(float), 256) : 0);
+           (wide_supported(d, sweeps_per_step) ? align_up((size_t)d->num_sweeps * d->C * kWideRec * sizeof(float), 256) : 0) +
+           (pde_adi_small_supported(d, sweeps_per_step) ? align_up(state_bytes(d), 256) : 0);
 }
 
 // zero + factorise every sweep into a steps workspace; the per-sweep maxima optionally also straight into the caller's
@@ -1138,7 +1141,7 @@ static int small_split(const PdeAdiDesc* d, int sps) {
 }
 static int small_grid(const PdeAdiDesc* d) { return d->B < 1024 ? d->B : 1024; }
 static int dispatch_small(bool fwd, const PdeAdiDesc* d, int split, const SmallArgs& sa, size_t lds, hipStream_t st) {
-    const int grid = small_grid(d);
+    const int grid = small_grid(d) * (sa.par ? sa.L : 1);
     switch (d->N) {
 #define PDE_SMALL_CASE(NN) case NN: return fwd ? adi_launch_small_fwd_##NN(d->io_dtype, split, &sa, grid, lds, st) \
                                                : adi_launch_small_bwd_##NN(d->io_dtype, split, &sa, grid, lds, st);
@@ -1177,6 +1180,17 @@ static void small_fill(SmallLayer& sl, const PdeAdiDesc* d, int sps, int mode, c
     sl.w = weight; sl.wp = weight_ptr;
 }
 
+// Layers that share an input run side by side (one layer per workgroup) while the batch alone does not fill the chip:
+// the three cifar10 layers on 128 samples are 128 workgroups of 3 waves each walking 51 sweeps one after the other
+static int multi_parallel(int32_t L, const PdeAdiDesc* d) { return (L > 1 && d->B < 1024) ? 1 : 0; }
+static int combine_slabs(const PdeAdiDesc* d, const SmallArgs& sa, void* out, hipStream_t st) {
+    CombineArgs ca{};
+    for (int i = 0; i < sa.L; ++i) ca.slab[i] = sa.layer[i].slab;
+    ca.out = out; ca.L = sa.L;
+    ca.n4 = (size_t)d->B * d->C * d->N * d->N / 4;
+    return d->io_dtype == PDE_IO_F32 ? small_combine_io<float>(ca, st) : small_combine_io<bf16_t>(ca, st);
+}
+
 // layers of one launch must agree on everything the kernel instantiation and the grid depend on
 static int multi_check(int32_t L, const PdeSmallLayer* layers) {
     if (L < 1 || L > kSmallMaxL || !layers) return PDE_E_BADARG;
@@ -1203,6 +1217,7 @@ int pde_adi_multi_forward(int32_t num_layers, const PdeSmallLayer* layers, const
     const PdeAdiDesc* d0 = layers[0].desc;
     SmallArgs sa{};
     sa.u = u; sa.out = out; sa.B = d0->B; sa.C = d0->C; sa.L = num_layers;
+    sa.par = multi_parallel(num_layers, d0);
     for (int i = 0; i < num_layers; ++i) {
         const PdeSmallLayer& y = layers[i];
         bool wrote = false;
@@ -1214,9 +1229,12 @@ int pde_adi_multi_forward(int32_t num_layers, const PdeSmallLayer* layers, const
         small_fill(sa.layer[i], y.desc, y.sweeps_per_step, y.mode, y.steps_workspace, y.M, y.skip_weight, y.weight, y.weight_ptr);
         sa.layer[i].states = y.states;
         sa.layer[i].psum = y.plane_sums;
+        sa.layer[i].slab = static_cast<char*>(y.steps_workspace) + steps_wide_offset(y.desc, y.sweeps_per_step);
     }
     if (kappa_event && hipEventRecord(static_cast<hipEvent_t>(kappa_event), st) != hipSuccess) return PDE_E_LAUNCH;
-    return dispatch_small(true, d0, small_split(d0, layers[0].sweeps_per_step), sa, small_lds_fwd(d0->C), st);
+    rc = dispatch_small(true, d0, small_split(d0, layers[0].sweeps_per_step), sa, small_lds_fwd(d0->C), st);
+    if (rc != PDE_OK || !sa.par) return rc;
+    return combine_slabs(d0, sa, out, st);
 }
 
 size_t pde_adi_small_backward_workspace_bytes(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t num_checkpoints) {
@@ -1224,6 +1242,7 @@ size_t pde_adi_small_backward_workspace_bytes(const PdeAdiDesc* d, int32_t sweep
     const int G = small_grid(d), K = d->num_sweeps / sweeps_per_step;
     return align_up((size_t)G * d->C * 4 * kImage * sizeof(float), 256) +
            align_up((size_t)G * d->C * kGmStride * sizeof(float), 256) +
+           align_up(state_bytes(d), 256) +                 // this layer's term of a shared-input group's input gradient
            align_up((size_t)K * num_checkpoints * d->B * d->C * d->N * d->N * sizeof(float), 256);
 }
 
@@ -1237,6 +1256,7 @@ int pde_adi_multi_backward(int32_t num_layers, const PdeSmallLayer* layers, cons
     const int sps = layers[0].sweeps_per_step, G = small_grid(d0), split = small_split(d0, sps);
     SmallArgs sa{};
     sa.u = u; sa.gy = gy; sa.out = gu; sa.B = d0->B; sa.C = d0->C; sa.L = num_layers;
+    sa.par = multi_parallel(num_layers, d0);
     bool any_ck = false;
     for (int i = 0; i < num_layers; ++i) {
         const PdeSmallLayer& y = layers[i];
@@ -1256,6 +1276,7 @@ int pde_adi_multi_backward(int32_t num_layers, const PdeSmallLayer* layers, cons
         char* ws = static_cast<char*>(y.workspace);
         sl.part = reinterpret_cast<float*>(ws);            ws += align_up((size_t)G * d0->C * 4 * kImage * sizeof(float), 256);
         sl.gm_part = reinterpret_cast<float*>(ws);         ws += align_up((size_t)G * d0->C * kGmStride * sizeof(float), 256);
+        sl.slab = ws;                                      ws += align_up(state_bytes(d0), 256);
         sl.ckpt = nck ? reinterpret_cast<float*>(ws) : nullptr;
         sl.nck = nck;
         sl.ck[0] = nck ? y.ckpt_mask[0] : 0ull; sl.ck[1] = nck ? y.ckpt_mask[1] : 0ull;
@@ -1273,6 +1294,7 @@ int pde_adi_multi_backward(int32_t num_layers, const PdeSmallLayer* layers, cons
         sa.layer[i].roff = layers[i].g_plane_sums;
     }
     rc = dispatch_small(false, d0, split, sa, small_lds_bwd(d0->C), st);
+    if (rc == PDE_OK && sa.par) rc = combine_slabs(d0, sa, gu, st);
     if (rc != PDE_OK) return rc;
     for (int i = 0; i < num_layers; ++i) {
         const PdeSmallLayer& y = layers[i];

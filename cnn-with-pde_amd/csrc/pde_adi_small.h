@@ -49,12 +49,15 @@ struct SmallLayer {
     float step_scale;       // (1+eps)^-(sweeps per step): undoes the factor the adjoint solves carry
     float w;                // weight of this layer's output in `out` ...
     const float* wp;        // ... or, when not null, a device scalar holding it
+    void* slab;             // par: (B,C,N,N) of the tensor type: this layer's term of `out` (fwd) / `gu` (bwd)
 };
 struct SmallArgs {
     const void* u;          // the layers' common input (B,C,N,N)
     const void* gy;         // bwd: dL/dout (null: only the gys of the layers)
     void* out;              // fwd: sum_i w_i y_i (null: checkpoint pre-pass only); bwd: gu
-    int B, C, L, pad;
+    int B, C, L;
+    int par;                // 1: the layers run side by side, workgroup x works on layer x % L of sample x / L, and writes
+                            // its term of `out` / `gu` to the layer's slab; small_combine_kernel adds the slabs up
     SmallLayer layer[kSmallMaxL];
 };
 // The layer descriptors are read where they lie, in the kernel-argument segment, with scalar loads at a run-time
@@ -129,9 +132,14 @@ __global__ __launch_bounds__(64 * kSmallMaxC) void adi_small_fwd_kernel(SmallArg
         }
     };
 
+    // layers one after the other in every workgroup, or (par) side by side: one layer per workgroup
+    const int lsel = a.par ? (int)(blockIdx.x % (unsigned)a.L) : -1;
+    const int b0 = a.par ? (int)(blockIdx.x / (unsigned)a.L) : (int)blockIdx.x;
+    const int bstep = a.par ? (int)(gridDim.x / (unsigned)a.L) : (int)gridDim.x;
     int cur = 0;
-    dma_rec(0, small_layer(0)->coef, 0);
+    dma_rec(0, small_layer(lsel < 0 ? 0 : lsel)->coef, 0);
     for (int li = 0; li < a.L; ++li) {
+        if (lsel >= 0 && li != lsel) continue;
         const ConstLayer Lp = small_layer(li);
         const float* coef = Lp->coef;
         const float* Mp = Lp->M;
@@ -143,8 +151,9 @@ __global__ __launch_bounds__(64 * kSmallMaxC) void adi_small_fwd_kernel(SmallArg
         const int nck = Lp->nck, K = Lp->K, mode = Lp->mode, S = K * SPS;
         const float* wpp = Lp->wp;
         const float wl = wpp ? *wpp : Lp->w;
-        const bool last_layer = li + 1 == a.L;
+        const bool last_layer = li + 1 == a.L || lsel >= 0;
         const float* coef_next = last_layer ? small_layer(0)->coef : small_layer(li + 1)->coef;
+        IO* yl = (lsel >= 0 && y != nullptr) ? static_cast<IO*>(Lp->slab) : y;      // where my term of the output goes
         float mrow[kSmallMaxC];                                           // my row of the operator
 #pragma unroll
         for (int j = 0; j < kSmallMaxC; ++j) mrow[j] = (j < nC) ? Mp[c * nC + j] : 0.f;
@@ -170,8 +179,8 @@ __global__ __launch_bounds__(64 * kSmallMaxC) void adi_small_fwd_kernel(SmallArg
             for (int k = 0; k < M; ++k) v[k] = acc[k];
         };
 
-        for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
-            const bool last_sample = b + (int)gridDim.x >= a.B;
+        for (int b = b0; b < a.B; b += bstep) {
+            const bool last_sample = b + bstep >= a.B;
             float v[M], u0[M];
             small_load<N, 0, IO>(u, b, nC, c, lane, l, hf, T, u0);
 #pragma unroll
@@ -221,7 +230,7 @@ __global__ __launch_bounds__(64 * kSmallMaxC) void adi_small_fwd_kernel(SmallArg
                     if (lane == 0) psum[(size_t)b * nC + c] = t;
                 }
                 if (a.L > 1) {                                            // out = sum_i w_i y_i: my own earlier store, re-read
-                    if (li > 0) {
+                    if (li > 0 && lsel < 0) {
                         float o[M];
                         small_load<N, 0, IO>(y, b, nC, c, lane, l, hf, T, o);
 #pragma unroll
@@ -231,11 +240,25 @@ __global__ __launch_bounds__(64 * kSmallMaxC) void adi_small_fwd_kernel(SmallArg
                         for (int q = 0; q < M; ++q) v[q] = wl * v[q];
                     }
                 }
-                small_store<N, 0, IO>(y, b, nC, c, lane, l, hf, T, v);
+                small_store<N, 0, IO>(yl, b, nC, c, lane, l, hf, T, v);
             }
         }
     }
     dma_wait_all();
+}
+
+// out = slab_0 + slab_1 + ... in this order (the layers' terms of the weighted sum / of the input gradient)
+struct CombineArgs { const void* slab[kSmallMaxL]; void* out; int L; size_t n4; };
+template <typename IO>
+__global__ __launch_bounds__(256) void small_combine_kernel(CombineArgs a) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n4) return;
+    float4 s = IoTraits<IO>::load4(static_cast<const IO*>(a.slab[0]) + 4 * i);
+    for (int k = 1; k < a.L; ++k) {
+        const float4 t = IoTraits<IO>::load4(static_cast<const IO*>(a.slab[k]) + 4 * i);
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    IoTraits<IO>::store4(static_cast<IO*>(a.out) + 4 * i, s);
 }
 
 // ---- backward --------------------------------------------------------------------------------------------
@@ -303,9 +326,13 @@ __global__ __launch_bounds__(64 * kSmallMaxC) void adi_small_bwd_kernel(SmallArg
         }
     };
 
+    const int lsel = a.par ? (int)(blockIdx.x % (unsigned)a.L) : -1;
+    const int b0 = a.par ? (int)(blockIdx.x / (unsigned)a.L) : (int)blockIdx.x;
+    const int bstep = a.par ? (int)(gridDim.x / (unsigned)a.L) : (int)gridDim.x;
     int cur = 0;
-    dma_rec(0, small_layer(0)->coef, small_layer(0)->K * SPS - 1);
+    dma_rec(0, small_layer(lsel < 0 ? 0 : lsel)->coef, small_layer(lsel < 0 ? 0 : lsel)->K * SPS - 1);
     for (int li = 0; li < a.L; ++li) {
+        if (lsel >= 0 && li != lsel) continue;
         const ConstLayer Lp = small_layer(li);
         const float* coef = Lp->coef;
         const SweepTab* tabs = Lp->tabs;
@@ -319,8 +346,9 @@ __global__ __launch_bounds__(64 * kSmallMaxC) void adi_small_bwd_kernel(SmallArg
         const int nck = Lp->nck, K = Lp->K, mode = Lp->mode, S = K * SPS, smooth = Lp->smooth3;
         const float* wpp = Lp->wp;
         const float wl = wpp ? *wpp : Lp->w, step_scale = Lp->step_scale;
-        const bool last_layer = li + 1 == a.L;
+        const bool last_layer = li + 1 == a.L || lsel >= 0;
         const ConstLayer Ln = small_layer(last_layer ? 0 : li + 1);
+        IO* gul = lsel >= 0 ? static_cast<IO*>(Lp->slab) : gu;             // where my term of the input gradient goes
         const float* coef_next = Ln->coef;
         const int s_next = Ln->K * SPS - 1;
         const bool masked = as_const(Lp->varying)[c] != 0;                // wave-uniform: my channel's clamp mask moves in time
@@ -375,8 +403,8 @@ __global__ __launch_bounds__(64 * kSmallMaxC) void adi_small_bwd_kernel(SmallArg
             for (int k = 0; k < M; ++k) r[k] = racc[k];
         };
 
-        for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
-            const bool last_sample = b + (int)gridDim.x >= a.B;
+        for (int b = b0; b < a.B; b += bstep) {
+            const bool last_sample = b + bstep >= a.B;
             float r[M], x[M], gsk[M], g0[M];
             if (gy != nullptr) small_load<N, 0, IO>(gy, b, nC, c, lane, l, hf, T, g0);
             else {
@@ -449,18 +477,18 @@ __global__ __launch_bounds__(64 * kSmallMaxC) void adi_small_bwd_kernel(SmallArg
             }
 #pragma unroll
             for (int q = 0; q < M; ++q) r[q] += gsk[q];                  // the skip branch's share of dL/du
-            if (li > 0) {                                                 // gu = sum over the layers: my own earlier store
+            if (li > 0 && lsel < 0) {                                     // gu = sum over the layers: my own earlier store
                 float o[M];
                 small_load<N, 0, IO>(gu, b, nC, c, lane, l, hf, T, o);
 #pragma unroll
                 for (int q = 0; q < M; ++q) r[q] += o[q];
             }
-            small_store<N, 0, IO>(gu, b, nC, c, lane, l, hf, T, r);
+            small_store<N, 0, IO>(gul, b, nC, c, lane, l, hf, T, r);
         }
 
         // my channel's sums of this layer: this workgroup's slot of the partial buffers (one wave per channel: nothing
         // to add up here)
-        float* dst = Lp->part + ((size_t)blockIdx.x * nC + c) * 4 * kImage + l * kLineStride + hf * kHalfPad;
+        float* dst = Lp->part + ((size_t)b0 * nC + c) * 4 * kImage + l * kLineStride + hf * kHalfPad;
 #pragma unroll
         for (int arr = 0; arr < 4; ++arr) {
 #pragma unroll
@@ -471,7 +499,7 @@ __global__ __launch_bounds__(64 * kSmallMaxC) void adi_small_bwd_kernel(SmallArg
                 *reinterpret_cast<float4*>(dst + arr * kImage + 4 * i) = v4;
             }
         }
-        float* gd = Lp->gm_part + ((size_t)blockIdx.x * nC + c) * kGmStride;
+        float* gd = Lp->gm_part + ((size_t)b0 * nC + c) * kGmStride;
 #pragma unroll
         for (int j = 0; j < kGmStride; ++j) {
             float v = (j < kSmallMaxC) ? gm[j] : (j == kSmallMaxC ? gskip : wsum);
@@ -480,6 +508,12 @@ __global__ __launch_bounds__(64 * kSmallMaxC) void adi_small_bwd_kernel(SmallArg
         }
     }
     dma_wait_all();
+}
+
+template <typename IO>
+int small_combine_io(const CombineArgs& ca, hipStream_t st) {
+    hipLaunchKernelGGL(small_combine_kernel<IO>, dim3((unsigned)((ca.n4 + 255) / 256)), dim3(256), 0, st, ca);
+    return check_launch();
 }
 
 template <int N, typename IO>

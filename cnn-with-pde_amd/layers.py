@@ -86,7 +86,33 @@ class _AdiBase(nn.Module):
             old = (km, plan(km.host.tolist()))
         elif old[0].event.query():
             old = (old[0], plan(old[0].host.tolist()))
+        seen = self.__dict__.get("_plans_seen")
+        if seen is not None:                                 # freeze_checkpoint_plan() is listening
+            seen.append(old[1])
         return old, cache, key
+
+    def freeze_checkpoint_plan(self, example):
+        """Pin the checkpoint plan to an explicit mask made from the CURRENT parameters (one synchronous wait; the
+        conservative budget of the lagged policy).  A call with an explicit mask issues launches only — no wait
+        for the coefficient maxima, no host copy — which is what hipGraph capture needs (``graphs.py``).  The mask
+        stays valid while the coefficients do not grow by more than the budget's margin (a factor 2 in error
+        amplification); call again after large parameter changes.  ``example``: a tensor like the layer's input."""
+        self.__dict__.pop("_kmax_cache", None)
+        seen = self.__dict__["_plans_seen"] = []
+        old = self.checkpoint_policy
+        self.checkpoint_policy = "lagged"
+        try:
+            with torch.enable_grad():
+                self(example.detach().clone().requires_grad_(True))
+        finally:
+            self.checkpoint_policy = old
+            self.__dict__.pop("_plans_seen", None)
+            self.__dict__.pop("_kmax_cache", None)
+        mask = 0
+        for m in seen:
+            mask |= int(m)
+        self.checkpoint_policy = mask
+        return mask
 
     def _diffuse(self, u, sweeps):
         args = (self.alpha_base, self.beta_base, self.alpha_time_coeff, self.beta_time_coeff)

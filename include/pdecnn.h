@@ -212,8 +212,10 @@ int pde_adi_small_backward(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t
  * cifar10.py:272-274 runs three EnhancedDiffusionLayers (5, 8 and 4 steps with their own dt/dx and their own
  * parameters) on the same x and combines them with softmax weights (:277-280); cifar_2version.py:287-288 two.
  * pde_adi_multi_forward runs up to 4 such layers (C <= 4, mode 1) inside one launch — every workgroup walks its
- * samples through layer after layer — and writes out = sum_i weight_i * y_i; the y_i themselves are the last of
- * each layer's `states`.  One layer with weight 1 is pde_adi_small_forward.
+ * samples through layer after layer, or, while the batch alone does not fill the chip (B < 1024), the layers run side
+ * by side (one layer per workgroup; the terms of `out` / `gu` meet in a small second launch, in a fixed order) — and
+ * writes out = sum_i weight_i * y_i; the y_i themselves are the last of each layer's `states`.  One layer with
+ * weight 1 is pde_adi_small_forward.
  * The backward takes gy = dL/dout and/or per layer gys = dL/dy_i, and gives gu = sum_i gu_i, every layer's
  * parameter gradients, and g_weight = <gy, y_i>. */
 typedef struct PdeSmallLayer {
