@@ -143,7 +143,7 @@ def config_legs(dev, rank, world, dist_on, quick):
     import cnn_with_pde_amd as P
     legs = {}
 
-    def leg(name, layer, shape, dtype, bpe, steps, desc):
+    def leg(name, layer, shape, dtype, bpe, steps, desc, graph=False):
         layer = layer.to(dev)
         g = torch.Generator().manual_seed(4321 + rank)
         u = torch.randn(*shape, generator=g).to(dtype).to(dev).requires_grad_(True)
@@ -157,6 +157,27 @@ def config_legs(dev, rank, world, dist_on, quick):
                           "steps": steps, "ms_per_step": ms, "value": shape[0] * world / (dt / steps) / 1e6,
                           "unit": "Msamples/s", "algorithmic_GBps_per_gpu": gbs, "frac": gbs / HBM_PEAK_GBS,
                           "bytes_per_element": bpe}
+        if graph and not dist_on:
+            # host-bound shapes: the same forward+backward captured once in a hipGraph and replayed (cnn_with_pde_amd.graphs)
+            try:
+                layer.freeze_checkpoint_plan(u)
+                params = list(layer.parameters())
+                step = P.GraphedStep(lambda: torch.autograd.grad(layer(u), [u] + params, gy))
+                for _ in range(5):
+                    step()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(4 * steps):
+                    step()
+                torch.cuda.synchronize()
+                gms = (time.perf_counter() - t0) / (4 * steps) * 1e3
+                if rank == 0:
+                    legs[name]["ms_per_step_hipgraph_replay"] = gms
+                    legs[name]["frac_hipgraph_replay"] = u.numel() * bpe / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                del step
+            except Exception as e:                             # reported, never fatal for the bench line
+                if rank == 0:
+                    legs[name]["ms_per_step_hipgraph_replay"] = "capture failed: %s" % (str(e)[:120],)
         del layer, u, gy
         torch.cuda.empty_cache()
 
@@ -174,9 +195,9 @@ def config_legs(dev, rank, world, dist_on, quick):
         c32.alpha_base.fill_(1.8); c32.beta_base.fill_(1.8); c32.alpha_time_coeff.zero_(); c32.beta_time_coeff.zero_()
         c32.channel_coupling.copy_(torch.eye(32)); c32.skip_weight.fill_(-40.0)
         c4.channel_coupling.copy_(torch.eye(128) + 0.01 * torch.randn(128, 128, generator=gp))
-    leg("cfg1", mn, (64, 1, 28, 28), torch.float32, 20, k, "mnist_test.DiffusionLayer(), batch 64 (BASELINE configs[0])")
+    leg("cfg1", mn, (64, 1, 28, 28), torch.float32, 20, k, "mnist_test.DiffusionLayer(), batch 64 (BASELINE configs[0])", graph=True)
     leg("cfg3_c1", fa, (4096, 1, 28, 28), torch.float32, 20, k,
-        "fashion_mnist.DiffusionLayer() literal C=1, batch 4096/GPU (BASELINE configs[2])")
+        "fashion_mnist.DiffusionLayer() literal C=1, batch 4096/GPU (BASELINE configs[2])", graph=True)
     leg("cfg3_c32", c32, (512, 32, 28, 28), torch.float32, 20, k,
         "SVHN.DiffusionLayer(28,32,dt=0.3,num_steps=4), fashion coefficients, coupling each step, batch 512/GPU")
     leg("cfg4_bf16", c4, (512, 128, 32, 32), torch.bfloat16, 10, max(3, k // 4),
