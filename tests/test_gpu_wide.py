@@ -135,3 +135,43 @@ def test_wide_forward_with_checkpointed_backward(kind, ck):
         errs["g_" + n] = G.rel_err(p.grad.cpu().reshape(gp_ref[n].shape), gp_ref[n])
     bad = {k: v for k, v in errs.items() if not v <= TOL}
     assert not bad, (bad, errs)
+
+
+def test_full_baseline_size_with_mixing_properties():
+    """BASELINE configs[1] as the reference runs it (512 x 64 x 32 x 32, mixing before each of the 10 Strang steps):
+    one-launch forward, per-step backward.  Size-independent properties: linearity in u, the adjoint identity,
+    parameter gradients (channel_mixing included) of two parts of the batch add up to those of the whole, and a
+    slice of the batch equals the same samples run alone."""
+    g = torch.Generator().manual_seed(2025)
+    layer, _ = _make("cifar10", 64, 32, 10, 0.001)
+    _randomise(layer, g)
+    layer = layer.cuda()
+    B = 512
+    u = torch.randn(B, 64, 32, 32, generator=g).cuda()
+    v = torch.randn(B, 64, 32, 32, generator=g).cuda()
+    gy = torch.randn(B, 64, 32, 32, generator=g).cuda()
+    with torch.no_grad():
+        yu, yv = layer(u), layer(v)
+        lhs = layer(2.0 * u - 0.5 * v)
+        rhs = 2.0 * yu - 0.5 * yv
+        assert float((lhs - rhs).abs().max() / rhs.abs().max()) <= 5e-6
+        assert torch.equal(layer(u[100:132]), yu[100:132])
+    del lhs, rhs, yv
+    ud = u.clone().requires_grad_(True)
+    y = layer(ud)
+    y.backward(gy)
+    a = float((y.detach().double() * gy.double()).sum())
+    b = float((ud.grad.double() * u.double()).sum())
+    assert abs(a - b) <= 1e-5 * float(y.detach().double().norm() * gy.double().norm())
+    full = {n: p.grad.clone() for n, p in layer.named_parameters()}
+    del y, ud
+    acc = {n: torch.zeros_like(t) for n, t in full.items()}
+    for sl in (slice(0, 200), slice(200, 512)):
+        for p in layer.parameters():
+            p.grad = None
+        uh = u[sl].clone().requires_grad_(True)
+        layer(uh).backward(gy[sl])
+        for n, p in layer.named_parameters():
+            acc[n] += p.grad
+    for n in full:
+        assert G.rel_err(acc[n].cpu(), full[n].cpu()) <= TOL, n
