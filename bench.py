@@ -82,6 +82,23 @@ def timed(layer, u, gy, steps, warmup, dist_on, flat):
     return dt
 
 
+def graph_replay_ms(layer, u, gy, reps):
+    """Forward + backward of ``layer`` on (u, gy) captured once in a hipGraph (cnn_with_pde_amd.graphs: checkpoint plan
+    frozen from the current coefficients, so the library's calls are launches only) and replayed ``reps`` times."""
+    import cnn_with_pde_amd as P
+    layer.freeze_checkpoint_plan(u)
+    params = [p_ for p_ in layer.parameters() if p_.requires_grad]
+    step = P.GraphedStep(lambda: torch.autograd.grad(layer(u), [u] + params, gy))
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
 def cpu_baseline(C, N, steps, sample_B):
     """The oracle in reference-faithful mode (per-unknown Python loop of torch ops, autograd
     backward — what the reference does) on this box's host cores, bounded sample: a 2-sample
@@ -160,21 +177,10 @@ def config_legs(dev, rank, world, dist_on, quick):
         if graph and not dist_on:
             # host-bound shapes: the same forward+backward captured once in a hipGraph and replayed (cnn_with_pde_amd.graphs)
             try:
-                layer.freeze_checkpoint_plan(u)
-                params = list(layer.parameters())
-                step = P.GraphedStep(lambda: torch.autograd.grad(layer(u), [u] + params, gy))
-                for _ in range(5):
-                    step()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(4 * steps):
-                    step()
-                torch.cuda.synchronize()
-                gms = (time.perf_counter() - t0) / (4 * steps) * 1e3
+                gms = graph_replay_ms(layer, u, gy, 4 * steps)
                 if rank == 0:
                     legs[name]["ms_per_step_hipgraph_replay"] = gms
                     legs[name]["frac_hipgraph_replay"] = u.numel() * bpe / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS
-                del step
             except Exception as e:                             # reported, never fatal for the bench line
                 if rank == 0:
                     legs[name]["ms_per_step_hipgraph_replay"] = "capture failed: %s" % (str(e)[:120],)
@@ -349,6 +355,15 @@ def main():
     copy_gbs = 20 * 2 * src.numel() / (time.perf_counter() - t0) / 1e9
     del src, dst
 
+    # the same step replayed from a hipGraph (extra information: `value` above is the eager autograd path)
+    graph_ms = None
+    if not dist_on:
+        try:
+            graph_ms = graph_replay_ms(layer, u, gy, a.steps)
+            layer.checkpoint_policy = "auto"
+        except Exception as e:
+            graph_ms = "capture failed: %s" % (str(e)[:120],)
+
     out = None
     if rank == 0:
         pmc, valu, pmc_src = None, None, None
@@ -370,6 +385,11 @@ def main():
                        "global_batch": B * world, "parallelism": f"dp{world}",
                        "grad_allreduce_bytes": (flat.nbytes() if flat is not None else 0),
                        "rccl_world_size": rccl_ws},
+            "hipgraph_replay": None if graph_ms is None else {
+                "ms_per_step": graph_ms,
+                "value": (B * world / (graph_ms * 1e-3) / 1e6) if isinstance(graph_ms, float) else None, "unit": "Msamples/s",
+                "note": "the same forward+backward captured once (cnn_with_pde_amd.graphs.GraphedStep, checkpoint plan "
+                        "frozen) and replayed: no Python/autograd/ctypes per step; `value` above is the eager path"},
             "roofline": {"bound": "hbm", "kernel": "adi_bwd_kernel", "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc, "traffic_source": pmc_src,
                          "copy_ceiling_measured": copy_gbs,
