@@ -341,23 +341,43 @@ __global__ __launch_bounds__(64 * W) void mix_bwd_fused_kernel(const IO* __restr
         for (int r = 0; r < 16; ++r) acc_m[t][r] = 0.f;
     const int per_sample = (HW + kGmKP - 1) / kGmKP;
     const long total = (long)B * per_sample;
+    // The next chunk's tile is fetched into registers while the MFMAs of the current one run.  All workgroups start
+    // together and every one of them alternated between waiting for its loads and multiplying: 768 x 32 KB in flight
+    // for a moment, then nothing (per-workgroup stamps: ~24 k cycles per chunk against 12 k of MFMA for the three
+    // waves of a SIMD and ~16 k of traffic at copy speed).
+    constexpr int ITER = C * (kGmKP / 4) / NT;
+    static_assert(C * (kGmKP / 4) % NT == 0, "the tile is a whole number of 16-byte pieces per thread");
+    float4 gq[ITER], uq[ITER];
+    auto fetch = [&](long chn) __attribute__((always_inline)) {
+        const int fb = (int)(chn / per_sample);
+        const int fp0 = (int)(chn % per_sample) * kGmKP;
+#pragma unroll
+        for (int i = 0; i < ITER; ++i) {
+            const int e = tid + i * NT;
+            const int c = e / (kGmKP / 4), c4 = e % (kGmKP / 4);
+            const int p = fp0 + 4 * c4;
+            const bool pv = p < HW && chn < total;
+            const size_t off = ((size_t)fb * C + c) * HW + p;
+            gq[i] = pv ? Io4<IO>::ld(g + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+            uq[i] = pv ? Io4<IO>::ld(u + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    fetch(blockIdx.x);
     for (long ch = blockIdx.x; ch < total; ch += nsplit) {
         const int b = (int)(ch / per_sample);
         const int p0 = (int)(ch % per_sample) * kGmKP;
         __syncthreads();                               // previous chunk fully consumed (and wfrag written)
-        for (int e = tid; e < C * (kGmKP / 4); e += NT) {
+#pragma unroll
+        for (int i = 0; i < ITER; ++i) {
+            const int e = tid + i * NT;
             const int c = e / (kGmKP / 4), c4 = e % (kGmKP / 4);
-            const int p = p0 + 4 * c4;
-            const bool pv = p < HW;
-            const size_t off = ((size_t)b * C + c) * HW + p;
-            const float4 gv = pv ? Io4<IO>::ld(g + off) : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 uv = pv ? Io4<IO>::ld(u + off) : make_float4(0.f, 0.f, 0.f, 0.f);
             float* dg = sg + c * kGmLd + 4 * c4;
             float* du = su + c * kGmLd + 4 * c4;
-            *reinterpret_cast<float2*>(dg) = make_float2(gv.x, gv.y); *reinterpret_cast<float2*>(dg + 2) = make_float2(gv.z, gv.w);
-            *reinterpret_cast<float2*>(du) = make_float2(uv.x, uv.y); *reinterpret_cast<float2*>(du + 2) = make_float2(uv.z, uv.w);
+            *reinterpret_cast<float2*>(dg) = make_float2(gq[i].x, gq[i].y); *reinterpret_cast<float2*>(dg + 2) = make_float2(gq[i].z, gq[i].w);
+            *reinterpret_cast<float2*>(du) = make_float2(uq[i].x, uq[i].y); *reinterpret_cast<float2*>(du + 2) = make_float2(uq[i].z, uq[i].w);
         }
         __syncthreads();
+        fetch(ch + nsplit);                            // in flight under the MFMAs below
         // gM: contraction index = pixel pair ks of the tile
 #pragma unroll 4
         for (int ks = 0; ks < kGmKP / 2; ++ks) {
