@@ -525,7 +525,12 @@ __global__ __launch_bounds__(kThreads, (sizeof(IO) < 4 ? 4 : 1)) void adi_fwd_ke
     // Phase skew (see "skew" in pde_adi.hip): the upper half of the waves runs ONE sweep behind the
     // lower half, so while one half is in a y sweep (re-layouts: LDS pipe) the other is in an x sweep
     // (VALU); in lock-step every wave wants the same pipe at the same time.
-    const int lag = wave_lag(wave);
+    // A launch of at most kRing sweeps (the per-step launches of the layers with a channel operator: 2 or 3) keeps ALL
+    // its records in the ring for the whole launch: no staging per sweep, no barrier per sweep, no skew — the waves of
+    // a workgroup run free of each other, so one wave's plane loads and stores overlap the others' sweeps (with a
+    // barrier per sweep every workgroup of the launch loaded, swept and stored in step with all the others).
+    const bool resident = a.S <= kRing;
+    const int lag = resident ? 0 : wave_lag(wave);
     young_half_priority(wave);
 
     // rows >= N of the wave images are never written: zero them once so idle lanes read zeros
@@ -544,7 +549,11 @@ __global__ __launch_bounds__(kThreads, (sizeof(IO) < 4 ? 4 : 1)) void adi_fwd_ke
             if (f < kRecFwd / 4) lds_dma16_s(rec + p * 256, 16u * lane, cbuf + (size_t)slot * kRecFwdPad + p * 256);
         }
     };
-    dma_rec(0, 0);
+    if (resident) {
+        for (int s = 0; s < a.S; ++s) dma_rec(s, s);
+    } else {
+        dma_rec(0, 0);
+    }
     dma_wait_all();
     __syncthreads();
     if (lag) {                                            // interval 0 of the upper waves: staging only
@@ -567,8 +576,8 @@ __global__ __launch_bounds__(kThreads, (sizeof(IO) < 4 ? 4 : 1)) void adi_fwd_ke
             if (sp >= a.S) sp -= a.S;
             int ps = cur + lag + 1;
             if (ps >= kRing) ps -= kRing;
-            dma_rec(ps, sp);
-            const float* rec = cbuf + cur * kRecFwdPad;
+            if (!resident) dma_rec(ps, sp);
+            const float* rec = cbuf + (resident ? s : cur) * kRecFwdPad;
             const int axs = (AX >= 0) ? AX : tab->axis[s];
             if (axs == PDE_AXIS_Y) relayout_all<N, J>(v, T, l, hf);
             if (!(decltype(TWINC)::value && a.pair_x != 0 && s != 0)) load_fwd_rows<M>(rec, l, hf, ce, cinv, cjn);
@@ -578,9 +587,11 @@ __global__ __launch_bounds__(kThreads, (sizeof(IO) < 4 ? 4 : 1)) void adi_fwd_ke
                 float* slot = a.ckpt + (size_t)ck_slot(a.ck, s) * a.B * a.C * plane;
                 store_planes<N, J, float>(slot, q, wave, lane, l, hf, a.B, a.C, c, T, v);
             }
-            dma_wait_all();                               // my pieces of the next record have landed
-            __syncthreads();
-            cur = (cur == kRing - 1) ? 0 : cur + 1;
+            if (!resident) {
+                dma_wait_all();                           // my pieces of the next record have landed
+                __syncthreads();
+                cur = (cur == kRing - 1) ? 0 : cur + 1;
+            }
         };
         if constexpr (SPLIT == kSplitStrang) {
             for (int s = 0; s < a.S; s += 3) {
@@ -764,7 +775,10 @@ __device__ __forceinline__ void adi_bwd_body(const SweepArgs& a, int blk) {
     const int first_x = tab->first_s[0], first_y = tab->first_s[1];
     const float tlast_x = tab->t_last[0], tlast_y = tab->t_last[1];
 
-    const int lag = ST::kStep ? wave_lag(wave) : 0;
+    // one time step per launch (the per-step launches of the layers with a channel operator): its SPS records stay in
+    // the ring for the whole launch and the waves run free of each other — see adi_fwd_kernel
+    const bool resident = ST::kStep && a.S == SPS;
+    const int lag = (ST::kStep && !resident) ? wave_lag(wave) : 0;
     // (no young_half_priority here: measured 6 % slower in the backward, 4.5 % faster in the forward)
     // record of sweep s -> ring slot `slot`
     auto dma_rec = [&](int slot, int s) __attribute__((always_inline)) {
@@ -875,7 +889,7 @@ __device__ __forceinline__ void adi_bwd_body(const SweepArgs& a, int blk) {
             int item = -LAG, s = a.S - 1, slot = 0;       // my next item, its sweep, its ring slot
 #pragma unroll 1
             for (int t = 0; t < nint; ++t) {
-                dma_next();
+                if (!resident) dma_next();
                 sfor<0, SPS>([&](auto IC) __attribute__((always_inline)) {
                     constexpr int pos = (decltype(IC)::value - LAG + SPS) % SPS;     // 0: newest sweep of a step
                     constexpr int AX = ((SPS - 1 - pos) == 1) ? PDE_AXIS_Y : PDE_AXIS_X;
@@ -896,10 +910,11 @@ __device__ __forceinline__ void adi_bwd_body(const SweepArgs& a, int blk) {
                             }
                         }
                         --s;
-                        slot = (slot + 1 == kSlots) ? 0 : slot + 1;
+                        slot = (slot + 1 == (resident ? SPS : kSlots)) ? 0 : slot + 1;
                     }
                     ++item;
                 });
+                if (resident) continue;                   // nothing staged, nothing shared: no wait, no barrier
 #ifdef PDE_STAMP
                 // every wave of one workgroup, intervals 2 and 3: work done, DMA landed, barrier passed
                 const bool tl_on = (blk == 5 && (t == 2 || t == 3) && lane == 0);
