@@ -6,7 +6,7 @@ for d in sys.argv[1:]:
         with open(f) as fh:
             for r in csv.DictReader(fh):
                 k = r["Kernel_Name"]
-                k = k.split("(")[0].replace("void pde::(anonymous namespace)::", "").replace("pde::(anonymous namespace)::", "")
+                k = k.replace("void pde::(anonymous namespace)::", "").replace("pde::(anonymous namespace)::", "").split("(")[0]
                 acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, cs in acc.items():
             if "adi_" not in k:
