@@ -87,6 +87,10 @@ SIGNATURES = {
                                            _vp, _vp]),
     "pde_gate_combine_backward": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                             _fp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _vp]),
+    "pde_bn_pool_workspace_bytes": (_sz, [_i32, _i32]),
+    "pde_bn_pool_forward": (C.c_int, [_i32, _i32, _i32, _fp, _fp, _fp, _f32, _i32, _f32, _fp, _fp, _fp, _fp, _fp, _vp, _vp, _sz,
+                                      _vp]),
+    "pde_bn_pool_backward": (C.c_int, [_i32, _i32, _i32, _fp, _fp, _fp, _fp, _vp, _fp, _i32, _fp, _fp, _fp, _vp, _sz, _vp]),
     "pde_channel_mix_forward": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _fp, _vp, _vp]),
     "pde_channel_mix_backward_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "pde_channel_mix_backward": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _fp, _vp, _fp, _vp, _sz, _vp]),

@@ -1,7 +1,7 @@
 """Public surface of cnn_with_pde_amd."""
 from . import _lib
 from ._lib import PdeError, LIB_PATH
-from .functional import (Sweep, adi_schedule, adi_diffuse, adi_diffuse_mixed, adi_diffuse_small, adi_diffuse_multi, gate_combine,
+from .functional import (Sweep, adi_schedule, adi_diffuse, adi_diffuse_mixed, adi_diffuse_small, adi_diffuse_multi, gate_combine, bn_pool,
                          plan_checkpoints, channel_mix, explicit5_step, jacobi_diffuse, timing_enable, timing_read)
 from .dist import shard_range, shard_batch, GradBucket
 from .layers import (MnistDiffusionLayer, FashionDiffusionLayer, SvhnDiffusionLayer, EnhancedDiffusionLayer,
@@ -47,7 +47,7 @@ def library_version() -> str:
 
 
 __all__ = ["graphs", "freeze_checkpoint_plans", "make_graphed", "GraphedStep", "PdeError", "LIB_PATH", "Sweep", "adi_schedule", "adi_diffuse", "adi_diffuse_mixed", "adi_diffuse_small",
-           "adi_diffuse_multi", "gate_combine", "plan_checkpoints", "channel_mix", "explicit5_step",
+           "adi_diffuse_multi", "gate_combine", "bn_pool", "plan_checkpoints", "channel_mix", "explicit5_step",
            "jacobi_diffuse", "timing_enable", "timing_read", "MnistDiffusionLayer", "FashionDiffusionLayer",
            "SvhnDiffusionLayer", "EnhancedDiffusionLayer", "LearnableDiffusionLayer", "ImprovedDiffusionLayer",
            "PDELayer", "models", "MnistPDEClassifier", "FashionPDEClassifier", "SvhnPDEClassifier", "SpatialAttention",

@@ -741,6 +741,70 @@ def channel_mix(u, M):
     return _MixFn.apply(u, M)
 
 
+# --------------------------------------------------------------------------- BatchNorm2d + 4x4 avg/max pooling
+class _BnPoolFn(torch.autograd.Function):
+    """cifar10.py:346-353 in two passes over the activation (pde_tail.hip): statistics, then normalise + pool."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps):
+        lib = L.load()
+        _require_cuda(x, gamma, beta)
+        B, Cc, N, _ = x.shape
+        xf = x.contiguous()
+        gm = None if gamma is None else gamma.detach().to(torch.float32).contiguous()
+        bt = None if beta is None else beta.detach().to(torch.float32).contiguous()
+        mean = torch.empty(Cc, dtype=torch.float32, device=x.device)
+        invstd = torch.empty_like(mean)
+        out = torch.empty((B, 2 * Cc, 4, 4), dtype=torch.float32, device=x.device)
+        amax = torch.empty((B, Cc, 4, 4), dtype=torch.int32, device=x.device)
+        ws = _workspace(lib.pde_bn_pool_workspace_bytes(B, Cc), x.device)
+        with torch.cuda.device(x.device):
+            L.check(lib.pde_bn_pool_forward(B, Cc, N, _ptr(xf), _ptr(gm), _ptr(bt), float(eps), 1 if training else 0,
+                                            float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(mean), _ptr(invstd),
+                                            _ptr(out), _ptr(amax), _ptr(ws), ws.numel(), _stream()), "pde_bn_pool_forward")
+        ctx.save_for_backward(xf, gm, mean, invstd, amax)
+        ctx.training = bool(training)
+        ctx.has = (gamma is not None, beta is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = L.load()
+        xf, gm, mean, invstd, amax = ctx.saved_tensors
+        B, Cc, N, _ = xf.shape
+        g = gout.to(torch.float32).contiguous()
+        gx = torch.empty_like(xf)
+        gg = torch.empty(Cc, dtype=torch.float32, device=xf.device)
+        gb = torch.empty_like(gg)
+        ws = _workspace(lib.pde_bn_pool_workspace_bytes(B, Cc), xf.device)
+        with torch.cuda.device(xf.device):
+            L.check(lib.pde_bn_pool_backward(B, Cc, N, _ptr(xf), _ptr(gm), _ptr(mean), _ptr(invstd), _ptr(amax), _ptr(g),
+                                             1 if ctx.training else 0, _ptr(gx), _ptr(gg), _ptr(gb), _ptr(ws), ws.numel(),
+                                             _stream()), "pde_bn_pool_backward")
+        return gx, (gg if ctx.has[0] else None), (gb if ctx.has[1] else None), None, None, None, None, None
+
+
+def bn_pool_supported(x, bn) -> bool:
+    """Whether ``bn_pool`` takes (x, bn): fp32 CUDA tensor (B,C,N,N), N a multiple of 4 up to 64, a BatchNorm2d with a
+    fixed momentum (or no running statistics)."""
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[2] == x.shape[3] and x.shape[2] % 4 == 0
+            and 4 <= x.shape[2] <= 64 and x.shape[0] > 0 and not torch.is_autocast_enabled()
+            and (bn.momentum is not None or not bn.track_running_stats)
+            and (bn.training or bn.running_mean is not None))
+
+
+def bn_pool(x, bn):
+    """``cat([adaptive_avg_pool2d(bn(x), 4), adaptive_max_pool2d(bn(x), 4)], dim=1)`` for a ``torch.nn.BatchNorm2d``
+    module ``bn`` (cifar10.py:346-353) without materialising ``bn(x)``: (B,C,N,N) -> (B,2C,4,4).  Updates the module's
+    running statistics in training mode exactly as the module would."""
+    training = bn.training or bn.running_mean is None
+    rm = bn.running_mean if (bn.track_running_stats and bn.training) or not training else None
+    rv = bn.running_var if (bn.track_running_stats and bn.training) or not training else None
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return _BnPoolFn.apply(x, bn.weight, bn.bias, rm, rv, training, bn.momentum if bn.momentum is not None else 0.0, bn.eps)
+
+
 # --------------------------------------------------------------------------- attention gates + weighted combination
 class _GateCombineFn(torch.autograd.Function):
     """combined = sum_i w_i gate_i[b,c] y_i — cifar10.py:242 (x * attention_weights) and :277-280 in one pass; the

@@ -208,10 +208,16 @@ class CIFAR10PDENoConv(nn.Module):
         self.classifier = EnhancedFC(96, [512, 256, 128, 64], 10, dropout_rate)
         self.feature_bn = nn.BatchNorm2d(3)
 
+    #: BatchNorm2d + the two 4x4 poolings in two passes over `combined` (functional.bn_pool) instead of torch's five
+    fused_tail = True
+
     def forward(self, x):
         combined = self.feature_extractor(x)[0]
-        feats = self.feature_bn(combined)
-        pooled = torch.cat([self.adaptive_pool(feats), self.max_pool(feats)], dim=1)
+        if self.fused_tail and F_.bn_pool_supported(combined, self.feature_bn):
+            pooled = F_.bn_pool(combined, self.feature_bn)                    # cifar10.py:346-353
+        else:
+            feats = self.feature_bn(combined)
+            pooled = torch.cat([self.adaptive_pool(feats), self.max_pool(feats)], dim=1)
         return self.classifier(pooled.view(pooled.size(0), -1))
 
 

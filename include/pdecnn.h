@@ -294,6 +294,24 @@ int pde_gate_combine_backward(int32_t L, int32_t B, int32_t C, int32_t HW, int32
                               const void* const* ys, const float* const* gates, const float* weights,
                               void* const* gys, float* const* dots, void* stream);
 
+/* ---- what follows the feature extractor in cifar10.CIFAR10PDENoConv ----------------------
+ * cifar10.py:346-353: features = BatchNorm2d(combined); pooled = cat([AdaptiveAvgPool2d(4,4)(features),
+ * AdaptiveMaxPool2d(4,4)(features)], dim=1).  `features` is never written: out (B,2C,4,4) fp32 comes straight from x
+ * (B,C,N,N) fp32, N a multiple of 4 and <= 64.  training != 0: statistics of the batch (biased variance for the
+ * normalisation; running_mean / running_var, when given, updated with `momentum` and the unbiased variance, as
+ * torch.nn.BatchNorm2d does); else the running statistics.  gamma / beta may be NULL (1 / 0).  mean, invstd: (C)
+ * outputs the backward needs, argmax: (B,C,4,4) int32 positions of the maxima inside their planes.
+ * backward: gout (B,2C,4,4) -> gx, ggamma, gbeta (all overwritten). */
+size_t pde_bn_pool_workspace_bytes(int32_t B, int32_t C);
+int pde_bn_pool_forward(int32_t B, int32_t C, int32_t N, const float* x, const float* gamma, const float* beta,
+                        float eps, int32_t training, float momentum, float* running_mean, float* running_var,
+                        float* mean, float* invstd, float* out, int32_t* argmax,
+                        void* workspace, size_t workspace_bytes, void* stream);
+int pde_bn_pool_backward(int32_t B, int32_t C, int32_t N, const float* x, const float* gamma, const float* mean,
+                         const float* invstd, const int32_t* argmax, const float* gout, int32_t training,
+                         float* gx, float* ggamma, float* gbeta,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- K2: explicit 5-point layers --------------------------- */
 
 /* tiny_imagenet.py:34-72: `num_steps` relaxed explicit steps (the reference's loop :44-49), each
