@@ -230,6 +230,17 @@ class _KmaxOwned:
         self.host, self.event = host, event
 
 
+def _wait_event(ev, spins=4000):
+    """Wait for an event that is expected within microseconds (the factorisation kernel right behind the forward's
+    launch): poll it before blocking — a blocking hipEventSynchronize costs the host ~100-150 us to wake up, more than
+    the whole backward of a small layer takes to launch."""
+    q = ev.query
+    for _ in range(spins):
+        if q():
+            return
+    ev.synchronize()
+
+
 class _KmaxTicket:
     """One use of a ring entry: ``host`` / ``event`` as long as the entry has not been handed out again."""
     __slots__ = ("entry", "gen", "n")
@@ -254,7 +265,7 @@ class _KmaxTicket:
 
     def wait(self):
         """Values once the copy has landed (waits for the factorisation kernel only)."""
-        self.event.synchronize()
+        _wait_event(self.event)
         return self.host.tolist()
 
 
@@ -547,7 +558,7 @@ class _AdiMultiFn(torch.autograd.Function):
         B, Cc, N, _ = u.shape
         arr = (L.PdeSmallLayer * nl)()
         if ctx.ckpt == "auto":
-            ctx.keep[-1][5].event.synchronize()
+            _wait_event(ctx.keep[-1][5].event)
         outs, hold = [], []
         gout_c = None if gout is None else gout.to(u.dtype).contiguous()
         for i in range(nl):
