@@ -1376,6 +1376,6 @@ int pde_timing_read(double* fwd_ms_sum, int64_t* fwd_launches, double* bwd_ms_su
     return PDE_OK;
 }
 
-const char* pde_version(void) { return "pdecnn-hip 0.3 (gfx950)"; }
+const char* pde_version(void) { return "pdecnn-hip 0.4 (gfx950)"; }
 
 }  // extern "C"
