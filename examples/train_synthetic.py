@@ -88,6 +88,57 @@ def synthetic_task(variant, classes, gen):
     return F.interpolate(coarse, size=(n, n), mode="bilinear", align_corners=False)        # smooth class templates
 
 
+def train_graphed(a, model, templates, classes, crit, gen, dev):
+    """The whole step as one hipGraph (cnn_with_pde_amd.graphs + torch's capturable AdamW): the PDE layers' calls are
+    launches only once their checkpoint plans are explicit, so nothing in the step needs the host.  The plans are
+    re-derived from the current coefficients every --log-every steps and the step is captured again if they changed."""
+    static_x = torch.zeros(a.batch, *templates.shape[1:], device=dev)
+    static_y = torch.zeros(a.batch, dtype=torch.long, device=dev)
+    opt = torch.optim.AdamW(model.parameters(), lr=a.lr, weight_decay=1e-4, capturable=True)
+    state = {}
+
+    def one_step():
+        opt.zero_grad(set_to_none=False)
+        out = model(static_x)
+        loss = crit(out, static_y)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
+        opt.step()
+        return loss, out
+
+    def capture():
+        plans = P.freeze_checkpoint_plans(model, static_x)
+        state["plans"] = {id(k): v for k, v in plans.items()}
+        state["step"] = P.GraphedStep(one_step)
+
+    def fill():
+        labels = torch.randint(0, classes, (a.batch,), generator=gen, device=dev)
+        static_y.copy_(labels)
+        static_x.copy_(templates[labels] + 1.0 * torch.randn(a.batch, *templates.shape[1:], generator=gen, device=dev))
+
+    fill()
+    capture()
+    log, recaptures = [], 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for step in range(a.steps):
+        fill()
+        loss, out = state["step"]()
+        if step % a.log_every == 0 or step == a.steps - 1:
+            acc = (out.argmax(1) == static_y).float().mean().item()
+            log.append({"step": step, "loss": round(loss.item(), 4), "acc": round(acc, 3)})
+            print(f"step {step:5d}  loss {loss.item():.4f}  acc {acc:.3f}", flush=True)
+            now = {id(k): v for k, v in P.freeze_checkpoint_plans(model, static_x).items()}
+            if now != state["plans"]:                      # coefficients grew past the frozen plan's margin
+                capture()
+                recaptures += 1
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({"variant": a.variant, "n_gpus": 1, "steps": a.steps, "global_batch": a.batch, "hipgraph": True,
+                      "recaptures": recaptures, "samples_per_s": a.batch * a.steps / dt, "first": log[0], "last": log[-1]}))
+    return log
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--variant", choices=sorted(VARIANTS), default="mnist")
@@ -96,6 +147,9 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
     ap.add_argument("--lr", type=float, default=1e-3)
     ap.add_argument("--log-every", type=int, default=50)
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the whole training step (forward, loss, backward, clipping, AdamW) in a hipGraph and replay "
+                         "it; checkpoint plans frozen and re-checked every --log-every steps (single GPU, fp32)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -124,6 +178,11 @@ def main():
     crit = nn.CrossEntropyLoss(label_smoothing=0.1)
     bucket = P.GradBucket(model.parameters()) if world > 1 else None
     gen = torch.Generator(device=dev).manual_seed(1000 + rank)          # a different shard per rank
+
+    if a.graph:
+        if world > 1 or a.amp:
+            raise SystemExit("--graph: single GPU, fp32")
+        return train_graphed(a, model, templates, classes, crit, gen, dev)
 
     log, t0 = [], time.perf_counter()
     for step in range(a.steps):

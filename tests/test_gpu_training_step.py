@@ -31,6 +31,18 @@ def test_training_reduces_loss(variant, amp, monkeypatch):
     assert log[-1]["acc"] > 0.5, log
 
 
+@pytest.mark.parametrize("variant", ["mnist", "cifar10_noconv"])
+def test_whole_step_replayed_from_a_hipgraph_trains_like_the_eager_loop(variant, monkeypatch):
+    """--graph: forward, loss, backward, clipping and AdamW captured once (checkpoint plans frozen) and replayed."""
+    mod = _load()
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, "argv", ["train_synthetic.py", "--variant", variant, "--steps", "80", "--batch", "64",
+                                      "--log-every", "79", "--graph"])
+    log = mod.main()
+    assert log[-1]["loss"] < 1.2 and log[-1]["acc"] > 0.6, log          # (the first entry is logged after the warm-up steps)
+
+
 def test_layer_parameters_receive_updates():
     import cnn_with_pde_amd as P
     mod = _load()
