@@ -185,7 +185,11 @@ def main():
         return train_graphed(a, model, templates, classes, crit, gen, dev)
 
     log, t0 = [], time.perf_counter()
+    warm = min(20, a.steps // 4)                          # first steps: library load, allocator and ring warm-up
     for step in range(a.steps):
+        if step == warm:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
         labels = torch.randint(0, classes, (a.batch,), generator=gen, device=dev)
         x = templates[labels] + 1.0 * torch.randn(a.batch, *templates.shape[1:], generator=gen, device=dev)
         opt.zero_grad(set_to_none=True)
@@ -209,7 +213,7 @@ def main():
     dt = time.perf_counter() - t0
     if rank == 0:
         print(json.dumps({"variant": a.variant, "n_gpus": world, "steps": a.steps, "global_batch": a.batch * world,
-                          "samples_per_s": a.batch * world * a.steps / dt, "first": log[0], "last": log[-1]}))
+                          "samples_per_s": a.batch * world * (a.steps - warm) / dt, "first": log[0], "last": log[-1]}))
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
