@@ -245,6 +245,8 @@ def config_legs(dev, rank, world, dist_on, quick):
     # the same step replayed from a hipGraph (cnn_with_pde_amd.graphs): explicit checkpoint plans, launches only
     graph_ms = None
     try:
+        if dist_on:
+            raise RuntimeError("single-GPU runs only")
         for ly in trio:
             ly.freeze_checkpoint_plan(x)
         params = [p_ for ly in trio for p_ in ly.parameters()]
