@@ -387,7 +387,9 @@ __device__ __forceinline__ void relayout(P (&v)[Geo<N>::M], float* T, int l, int
         for (int k = 0; k < M; ++k) dst[k * kLineStride] = pk_get<C>(v[k]);
     }
     __builtin_amdgcn_wave_barrier();
-    const int myrow = (l < M) ? l : M + (N - 1 - l);
+    // (idle lanes, l >= N, read their own never-written row: the formula below would send them to rows of live data or,
+    // for N < 22, in front of the image — into whatever another wave or an unwritten ring tail holds, NaN included)
+    const int myrow = (l < M) ? l : (l < N ? M + (N - 1 - l) : l);
     const float* src = T + myrow * kLineStride + hf * kHalfPad;
 #pragma unroll
     for (int i = 0; i < (M + 3) / 4; ++i) {

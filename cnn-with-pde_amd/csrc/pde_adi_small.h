@@ -315,7 +315,8 @@ __global__ __launch_bounds__(64 * kSmallMaxC) void adi_small_bwd_kernel(SmallArg
     const IO* gy = static_cast<const IO*>(a.gy);
     IO* gu = static_cast<IO*>(a.out);
     const size_t tens = (size_t)a.B * nC * N * N;
-    const float live = (l < N) ? 1.0f : 0.0f;                             // idle lanes (N < 32) carry no data
+    const bool live = l < N;                                              // idle lanes (N < 32) carry no data — and whatever they
+                                                                          // hold (Inf, NaN) must not reach a sum: select, never multiply
 
     auto dma_rec = [&](int slot, const float* coef, int s) __attribute__((always_inline)) {
         const float* rec = coef + ((size_t)s * nC + c) * kRecStride + kBwdOff;
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(64 * kSmallMaxC) void adi_small_bwd_kernel(SmallArg
                         d = fmaf(r[k], w[k], d);
                         vfull[k] = fmaf(mrow[j], w[k], vfull[k]);         // the operator's output, recomputed (skip term)
                     }
-                    gm[j] = fmaf(live, d, gm[j]);
+                    gm[j] += live ? d : 0.f;
                 }
             }
             __syncthreads();
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(64 * kSmallMaxC) void adi_small_bwd_kernel(SmallArg
                 float u0[M];
                 small_load<N, 0, IO>(u, b, nC, c, lane, l, hf, T, u0);
 #pragma unroll
-                for (int k = 0; k < M; ++k) gskip = fmaf(live * gsk[k], u0[k] - vfull[k], gskip);
+                for (int k = 0; k < M; ++k) gskip += live ? gsk[k] * (u0[k] - vfull[k]) : 0.f;
             }
 #pragma unroll
             for (int k = 0; k < M; ++k) r[k] = racc[k];
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(64 * kSmallMaxC) void adi_small_bwd_kernel(SmallArg
                 for (int k = 0; k < M; ++k) r[k] += gi[k];
             }
             if (roff != nullptr) {                                        // ... and at its spatial sum (the average pool)
-                const float ro = live * roff[(size_t)b * nC + c];
+                const float ro = live ? roff[(size_t)b * nC + c] : 0.f;
 #pragma unroll
                 for (int k = 0; k < M; ++k) r[k] += ro;
             }
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(64 * kSmallMaxC) void adi_small_bwd_kernel(SmallArg
             if (mode == 1) {
                 small_load<N, 0, IO>(st + (size_t)(K - 1) * tens, b, nC, c, lane, l, hf, TX, x);   // = y_i
 #pragma unroll
-                for (int k = 0; k < M; ++k) wsum = fmaf(live * g0[k], x[k], wsum);              // d out / d w_i = y_i
+                for (int k = 0; k < M; ++k) wsum += live ? g0[k] * x[k] : 0.f;                   // d out / d w_i = y_i
             }
             for (int k = K - 1; k >= 0; --k) {
                 if (mode == 2) {                                          // SVHN: the coupling came after the sweeps

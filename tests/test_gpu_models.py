@@ -268,3 +268,36 @@ def test_counterpart_model_trains(name, make, shape, classes, amp):
              and torch.isfinite(p.grad).all() and not torch.equal(p.detach(), before[n])]
     unused = {"diff.beta_base"} if name == "tiny" else set()           # tiny_imagenet.py: beta_base is never used
     assert set(pde_names) - set(moved) <= unused, set(pde_names) - set(moved)
+
+
+def test_shared_input_layers_one_after_the_other_and_side_by_side_agree():
+    """Batches of 1024 and more keep the layers of a shared-input group one after the other inside every workgroup;
+    smaller ones run them side by side with a combining pass.  Both against one call per layer, on the same data."""
+    import cnn_with_pde_amd as P
+    g = torch.Generator().manual_seed(41)
+    N, C = 16, 3
+    layers = [quiet(P.EnhancedDiffusionLayer, N, C, dt=dt, num_steps=st, dx=dx, dy=dx).cuda()
+              for dt, st, dx in ((0.02, 2, 1.0), (0.05, 3, 2.0), (0.03, 1, 1.5))]
+    with torch.no_grad():
+        for ly in layers:
+            ly.alpha_base.mul_(1 + 0.2 * torch.randn(C, N, N, generator=g).cuda())
+            ly.alpha_time_coeff.copy_(0.2 * torch.randn(C, N, N, generator=g).cuda())
+            ly.channel_mixing.copy_((torch.eye(C) + 0.1 * torch.randn(C, C, generator=g)).cuda())
+    w = torch.softmax(torch.randn(3, generator=g), 0).cuda()
+    for B in (1100, 96):
+        u = torch.randn(B, C, N, N, generator=g).cuda()
+        gy = torch.randn(B, C, N, N, generator=g).cuda()
+        res = []
+        for fused in (True, False):
+            for ly in layers:
+                for p in ly.parameters():
+                    p.grad = None
+            ud = u.clone().requires_grad_(True)
+            if fused:
+                out, _ = P.diffuse_shared_input(layers, ud, w)
+            else:
+                out = sum(w[i] * layers[i](ud) for i in range(3))
+            out.backward(gy)
+            res.append([out.detach(), ud.grad] + [p.grad.clone() for ly in layers for p in ly.parameters()])
+        for a, b in zip(*res):
+            assert G.rel_err(a.cpu(), b.cpu()) <= 1e-5, B
