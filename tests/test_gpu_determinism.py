@@ -104,3 +104,38 @@ def test_shared_input_group_and_svhn_layer_are_deterministic_and_finite(N):
         sv.alpha_base.mul_(15.0)
         sv.beta_base.mul_(15.0)
     _repeat(_fwd_bwd(sv, u, gy))
+
+
+@pytest.mark.parametrize("size,steps,dtype", [(16, 2, torch.float32), (32, 1, torch.bfloat16), (64, 3, torch.float32),
+                                              (24, 2, torch.float32), (40, 1, torch.bfloat16)])
+def test_explicit_layers_are_deterministic_and_finite(size, steps, dtype):
+    import cnn_with_pde_amd as P
+    g = torch.Generator().manual_seed(5 + size)
+    layer = P.ImprovedDiffusionLayer(size, 6, num_steps=steps).cuda()
+    with torch.no_grad():
+        layer.alpha_base.copy_(0.02 + 0.2 * torch.rand(6, generator=g))     # some above the 0.15 clamp
+        layer.channel_scaling.copy_(1 + 0.2 * torch.randn(6, generator=g))
+    u = torch.randn(21, 6, size, size, generator=g).to(dtype).cuda()
+    gy = torch.randn(21, 6, size, size, generator=g).to(dtype).cuda()
+    _repeat(_fwd_bwd(layer, u, gy))
+    if size == 16:
+        pl = P.PDELayer(Nx=20, Ny=20).cuda()
+        with torch.no_grad():
+            for n, v in dict(alpha_w1=0.05, alpha_w2=0.02, alpha_w3=-0.01, beta_w1=0.04, beta_w2=0.015, beta_w3=0.01).items():
+                getattr(pl, n).fill_(v)
+        x = torch.randn(9, 1, 20, 20, generator=g).cuda()
+        _repeat(_fwd_bwd(pl, x, torch.randn(9, 1, 20, 20, generator=g).cuda()))
+
+
+@pytest.mark.parametrize("N", [12, 28])
+def test_bf16_tensors_are_deterministic_and_finite(N):
+    import cnn_with_pde_amd as P
+    g = torch.Generator().manual_seed(60 + N)
+    for C, mixing in ((4, True), (6, False), (32, True)):
+        layer = quiet(P.EnhancedDiffusionLayer, N, C, dt=0.05, num_steps=2, channel_mixing_enabled=mixing).cuda()
+        _perturb(layer, g, 0.3)
+        if not mixing:
+            layer.channel_mixing.requires_grad_(False)
+        u = torch.randn(19, C, N, N, generator=g).bfloat16().cuda()
+        gy = torch.randn(19, C, N, N, generator=g).bfloat16().cuda()
+        _repeat(_fwd_bwd(layer, u, gy), reps=3)
