@@ -60,19 +60,37 @@ __global__ __launch_bounds__(256) void tail_plane_stats_kernel(TailArgs a) {
     if (lane == 0) { a.part[2 * pc] = m; a.part[2 * pc + 1] = q; }
 }
 
-// per channel: combine the planes' (mean, M2) in batch order (Chan's update, double precision), running statistics
+// per channel: one wave; lane i combines the planes b = i, i+64, ... in order (Chan's update, double precision), then the
+// 64 partial (count, mean, M2) triples meet in a butterfly — a fixed order; running statistics by lane 0
+__device__ __forceinline__ double shfl_xor_f64(double v, int m) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_xor(lo, m, 64); hi = __shfl_xor(hi, m, 64);
+    return __hiloint2double(hi, lo);
+}
 __global__ __launch_bounds__(64) void tail_channel_stats_kernel(TailArgs a) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= a.C) return;
+    const int c = blockIdx.x, lane = threadIdx.x;
     const double n1 = (double)a.N * a.N;
     double cnt = 0.0, mean = 0.0, M2 = 0.0;
-    for (int b = 0; b < a.B; ++b) {
+    for (int b = lane; b < a.B; b += 64) {
         const double mb = a.part[2 * (b * a.C + c)], qb = a.part[2 * (b * a.C + c) + 1];
         const double delta = mb - mean, tot = cnt + n1;
         mean += delta * n1 / tot;
         M2 += qb + delta * delta * cnt * n1 / tot;
         cnt = tot;
     }
+    for (int m = 1; m < 64; m <<= 1) {
+        const double c2 = shfl_xor_f64(cnt, m), m2 = shfl_xor_f64(mean, m), q2 = shfl_xor_f64(M2, m);
+        const double tot = cnt + c2;
+        if (tot > 0.0) {
+            // symmetric in the two partners: both lanes of a pair end up with the same triple
+            const double delta = m2 - mean;
+            const double nm = (cnt * mean + c2 * m2) / tot;
+            M2 = M2 + q2 + delta * delta * cnt * c2 / tot;
+            mean = nm;
+            cnt = tot;
+        }
+    }
+    if (lane != 0) return;
     const double var = M2 / cnt;
     a.mean[c] = (float)mean;
     a.invstd[c] = (float)(1.0 / sqrt(var + (double)a.eps));
@@ -165,12 +183,11 @@ __global__ __launch_bounds__(256) void tail_bwd_sums_kernel(TailArgs a) {
     if (lane == 0) { a.part[2 * pc] = s0; a.part[2 * pc + 1] = s1; }
 }
 __global__ __launch_bounds__(64) void tail_bwd_channel_kernel(TailArgs a) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= a.C) return;
+    const int c = blockIdx.x, lane = threadIdx.x;
     double s0 = 0.0, s1 = 0.0;
-    for (int b = 0; b < a.B; ++b) { s0 += a.part[2 * (b * a.C + c)]; s1 += a.part[2 * (b * a.C + c) + 1]; }
-    a.gbeta[c] = (float)s0;
-    a.ggamma[c] = (float)s1;
+    for (int b = lane; b < a.B; b += 64) { s0 += a.part[2 * (b * a.C + c)]; s1 += a.part[2 * (b * a.C + c) + 1]; }
+    for (int m = 1; m < 64; m <<= 1) { s0 += shfl_xor_f64(s0, m); s1 += shfl_xor_f64(s1, m); }
+    if (lane == 0) { a.gbeta[c] = (float)s0; a.ggamma[c] = (float)s1; }
 }
 // backward pass 2: dL/dx
 __global__ __launch_bounds__(256) void tail_bwd_dx_kernel(TailArgs a) {
@@ -236,7 +253,7 @@ int pde_bn_pool_forward(int32_t B, int32_t C, int32_t N, const float* x, const f
     const dim3 planes((B * C + 3) / 4), chans((C + 63) / 64);
     if (training) {
         hipLaunchKernelGGL(tail_plane_stats_kernel, planes, dim3(256), 0, st, a);
-        hipLaunchKernelGGL(tail_channel_stats_kernel, chans, dim3(64), 0, st, a);
+        hipLaunchKernelGGL(tail_channel_stats_kernel, dim3(C), dim3(64), 0, st, a);
     } else {
         hipLaunchKernelGGL(tail_eval_stats_kernel, chans, dim3(64), 0, st, a);
     }
@@ -257,9 +274,9 @@ int pde_bn_pool_backward(int32_t B, int32_t C, int32_t N, const float* x, const 
     a.part = static_cast<float*>(workspace);
     a.B = B; a.C = C; a.N = N; a.training = training;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const dim3 planes((B * C + 3) / 4), chans((C + 63) / 64);
+    const dim3 planes((B * C + 3) / 4);
     hipLaunchKernelGGL(tail_bwd_sums_kernel, planes, dim3(256), 0, st, a);
-    hipLaunchKernelGGL(tail_bwd_channel_kernel, chans, dim3(64), 0, st, a);
+    hipLaunchKernelGGL(tail_bwd_channel_kernel, dim3(C), dim3(64), 0, st, a);
     hipLaunchKernelGGL(tail_bwd_dx_kernel, planes, dim3(256), 0, st, a);
     return check_launch();
 }
