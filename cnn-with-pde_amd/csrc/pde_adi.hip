@@ -791,7 +791,32 @@ size_t steps_tab_offset(const PdeAdiDesc* d) { return coef_bytes(d) + flag_bytes
 size_t steps_wide_offset(const PdeAdiDesc* d, int sps) {
     return steps_tab_offset(d) + align_up((size_t)(d->num_sweeps / sps) * sizeof(SweepTab), 256);
 }
-bool wide_supported(const PdeAdiDesc* d, int sps);
+// which compile-time step pattern every step of the schedule follows (kSplitAny: not all the same)
+int small_split(const PdeAdiDesc* d, int sps) {
+    PdeAdiDesc ds;
+    if (step_desc(d, sps, 0, ds) != PDE_OK) return kSplitAny;
+    const int sp = split_of(&ds);
+    for (int k = 1; k < d->num_sweeps / sps; ++k) {          // every step the same pattern
+        if (step_desc(d, sps, k, ds) != PDE_OK || split_of(&ds) != sp) return kSplitAny;
+    }
+    return sp;
+}
+
+// ---- C = 32 / 64 fp32: the whole forward in one launch (pde_adi_wide.h) ----
+bool wide_enabled() {
+    static const bool on = [] { const char* e = getenv("PDE_WIDE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+bool wide_supported(const PdeAdiDesc* d, int sps) {
+    if (!wide_enabled() || d->io_dtype != PDE_IO_F32 || (d->C != 32 && d->C != 64)) return false;
+    bool n_ok = false;
+#define PDE_WIDE_CASE(NN) n_ok |= (d->N == NN);
+    PDE_WIDE_N_LIST
+#undef PDE_WIDE_CASE
+    if (!n_ok || (sps != 2 && sps != 3) || d->num_sweeps % sps) return false;
+    const int sp = small_split(d, sps);
+    return (sp == kSplitStrang && sps == 3) || (sp == kSplitLie && sps == 2);
+}
 
 }  // namespace
 }  // namespace pde
@@ -988,24 +1013,6 @@ static size_t state_bytes(const PdeAdiDesc* d) {
     return (size_t)d->B * d->C * d->N * d->N * (d->io_dtype == PDE_IO_BF16 ? 2 : 4);
 }
 
-// ---- C = 32 / 64 fp32: the whole forward in one launch (pde_adi_wide.h) ----
-static int small_split(const PdeAdiDesc* d, int sps);
-namespace pde { namespace {
-static bool wide_enabled() {
-    static const bool on = [] { const char* e = getenv("PDE_WIDE"); return !(e && e[0] == '0'); }();
-    return on;
-}
-bool wide_supported(const PdeAdiDesc* d, int sps) {
-    if (!wide_enabled() || d->io_dtype != PDE_IO_F32 || (d->C != 32 && d->C != 64)) return false;
-    bool n_ok = false;
-#define PDE_WIDE_CASE(NN) n_ok |= (d->N == NN);
-    PDE_WIDE_N_LIST
-#undef PDE_WIDE_CASE
-    if (!n_ok || (sps != 2 && sps != 3) || d->num_sweeps % sps) return false;
-    const int sp = small_split(d, sps);
-    return (sp == kSplitStrang && sps == 3) || (sp == kSplitLie && sps == 2);
-}
-} }
 static int wide_forward(const PdeAdiDesc* d, int sps, int mode, const void* u, void* states, const float* M,
                         const void* steps_workspace, int keep, hipStream_t st) {
     WideArgs wa{};
@@ -1130,15 +1137,6 @@ int pde_adi_mixed_backward(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t
 // ---- the whole layer in ONE launch per pass: C <= 4 channels with a channel operator between the steps ----------
 // (pde_adi_small.h; the reference's own models: cifar10.py:253-258 C = 3 mixing before every step,
 // SVHN.py:238 C = 3 coupling after every step + skip blend)
-static int small_split(const PdeAdiDesc* d, int sps) {
-    PdeAdiDesc ds;
-    if (step_desc(d, sps, 0, ds) != PDE_OK) return kSplitAny;
-    const int sp = split_of(&ds);
-    for (int k = 1; k < d->num_sweeps / sps; ++k) {          // every step the same pattern
-        if (step_desc(d, sps, k, ds) != PDE_OK || split_of(&ds) != sp) return kSplitAny;
-    }
-    return sp;
-}
 static int small_grid(const PdeAdiDesc* d) { return d->B < 1024 ? d->B : 1024; }
 static int dispatch_small(bool fwd, const PdeAdiDesc* d, int split, const SmallArgs& sa, size_t lds, hipStream_t st) {
     const int grid = small_grid(d) * (sa.par ? sa.L : 1);
