@@ -188,3 +188,49 @@ def test_random_bf16_case_vs_oracle(case):
         errs["g_skip_weight"] = abs(float(dl.skip_weight.grad) - float(gp_ref["skip_weight"])) / scale
     bad = {k: v for k, v in errs.items() if not v <= 2e-2}
     assert not bad, (bad, errs)
+
+
+def _extractor_cases():
+    rng = random.Random(SEED + 3)
+    return [(rng.choice([16, 28, 32]), rng.choice([1, 2, 3, 4]), rng.choice([1, 2, 5, 33, 130, 1100]), rng.random() < 0.5)
+            for _ in range(max(6, CASES // 5))]
+
+
+@pytest.mark.parametrize("case", _extractor_cases(), ids=lambda c: "-".join(str(x) for x in c))
+def test_random_extractor_fused_vs_layer_by_layer(case):
+    """cifar10.MultiScaleExtractor's counterpart (three layers on one input, attention pool / gate / combination) with
+    the one-launch group + fused epilogue against one call per layer + torch epilogue, at random sizes and batches
+    (side-by-side and one-after-the-other arrangements), values and every gradient."""
+    import copy
+    import cnn_with_pde_amd as P
+    N, C, B, feats = case
+    g = torch.Generator().manual_seed(zlib.crc32(repr(case).encode()))
+    torch.manual_seed(zlib.crc32(repr(case).encode()) & 0x7FFFFFFF)
+    m1 = quiet(P.MultiScaleExtractor, N, C).cuda()
+    with torch.no_grad():
+        for n, p in m1.named_parameters():
+            if n.endswith("alpha_base") or n.endswith("beta_base"):
+                p.mul_(1 + 0.2 * torch.randn(p.shape, generator=g).cuda())
+            elif n.endswith("channel_mixing"):
+                p.copy_((torch.eye(C) + 0.1 * torch.randn(C, C, generator=g)).cuda())
+        m1.combine_weights.copy_(torch.randn(3, generator=g))
+    m1.return_features = feats
+    m2 = copy.deepcopy(m1)
+    m2.fused_epilogue = False
+    for ly in (m2.pde1, m2.pde2, m2.pde3):
+        ly.small_channel_kernels = False             # per-step launches, one layer at a time: nothing shared with m1's path
+    x = torch.randn(B, C, N, N, generator=g).cuda()
+    gy = torch.randn(B, C, N, N, generator=g).cuda()
+    res = []
+    for m in (m1, m2):
+        xd = x.clone().requires_grad_(True)
+        out = m(xd)
+        loss = (out[0] * gy).sum()
+        if feats and m is m1 or (feats and out[1] is not None):
+            loss = loss + sum((f * gy).sum() * 0.3 for f in out[1:] if f is not None)
+        loss.backward()
+        res.append([out[0].detach(), xd.grad] + [p.grad for _, p in sorted(m.named_parameters())])
+    scale = max(float(t.abs().max()) for t in res[1][2:])
+    for a, b, (n, _) in zip(res[0], res[1], [("out", 0), ("gx", 0)] + sorted(m1.named_parameters())):
+        err = float((a - b).abs().max()) / max(float(b.abs().max()), 1e-3 * scale if n not in ("out", "gx") else 1e-30)
+        assert err <= 1e-4, (n, err)
