@@ -102,3 +102,36 @@ def test_make_graphed_layer_trains_like_the_eager_one():
         for p in layer.parameters():
             p.grad = None
         x = x * 0.5 + 0.1
+
+
+@pytest.mark.parametrize("kind", ["cifar10_c32", "svhn_c32_checkpointed"])
+def test_graphed_step_of_a_wide_layer(kind):
+    """Layers with a channel operator at C = 32 (one-launch forward, per-step backward; with fashion-size coefficients
+    the backward parks states and recomputes the operator outputs the forward did not keep): captured and replayed
+    bitwise like the eager call."""
+    import cnn_with_pde_amd as P
+    g = torch.Generator().manual_seed(19)
+    if kind == "cifar10_c32":
+        layer = quiet(P.EnhancedDiffusionLayer, 28, 32, dt=0.02, num_steps=3).cuda()
+    else:
+        layer = P.SvhnDiffusionLayer(28, 32, dt=0.3, num_steps=2).cuda()
+        with torch.no_grad():
+            layer.alpha_base.fill_(1.8)
+            layer.beta_base.fill_(1.8)
+            layer.channel_coupling.copy_((torch.eye(32) + 0.05 * torch.randn(32, 32, generator=g)).cuda())
+    x = torch.randn(6, 32, 28, 28, generator=g).cuda().requires_grad_(True)
+    gy = torch.randn(6, 32, 28, 28, generator=g).cuda()
+    mask = layer.freeze_checkpoint_plan(x)
+    assert (mask != 0) == (kind == "svhn_c32_checkpointed")
+    params = list(layer.parameters())
+
+    def fn():
+        y = layer(x)
+        return (y,) + torch.autograd.grad(y, [x] + params, gy)
+
+    step = P.GraphedStep(fn)
+    eager = [t.clone() for t in fn()]
+    got = step()
+    torch.cuda.synchronize()
+    for a, b in zip(got, eager):
+        assert torch.equal(a, b)
