@@ -526,9 +526,10 @@ int env_int(const char* name, int dflt) {           // developer tuning knobs (t
 }
 bool use_xcd_map(const PdeAdiDesc* d) { return (d->C % 8) == 0 && env_int("PDE_XCD", 1) != 0; }
 int groups_per_channel(const PdeAdiDesc* d, int planes_per_iter, int wg_per_cu) {
+    if (wg_per_cu < 1) wg_per_cu = 1;
     const int nchunk = (d->B + planes_per_iter - 1) / planes_per_iter;
     int G = (256 * wg_per_cu + d->C - 1) / d->C;
-    G = env_int(wg_per_cu == 8 / kWaves ? "PDE_G_BWD" : "PDE_G_FWD", G);
+    G = env_int(planes_per_iter == kWaves * kJBwd ? "PDE_G_BWD" : "PDE_G_FWD", G);
     if (G < 1) G = 1;
     if (G > nchunk) G = nchunk;
     return G;
@@ -834,7 +835,7 @@ size_t pde_adi_backward_workspace_bytes(const PdeAdiDesc* d, int32_t num_checkpo
     if (check_desc(d) != PDE_OK || num_checkpoints < 0) return 0;
     const int G = groups_per_channel(d, kWaves * kJBwd, 8 / kWaves);
     size_t b = coef_bytes(d) + tab_bytes() + flag_bytes(d);
-    b += align_up((size_t)G * d->C * 4 * kImage * sizeof(float), 256) + 512;     // + diagnostics scratch
+    b += align_up((size_t)G * d->C * 4 * kImage * sizeof(float), 256) + 2048;    // + diagnostics scratch
     b += align_up((size_t)num_checkpoints * d->B * d->C * d->N * d->N * sizeof(float), 256);
     return b;
 }
@@ -879,7 +880,7 @@ int pde_adi_backward(const PdeAdiDesc* d, const void* gy, const void* y, const v
     SweepTab* tab = reinterpret_cast<SweepTab*>(ws);      ws += tab_bytes();
     int* varying = reinterpret_cast<int*>(ws);            ws += flag_bytes(d);
     float* part = reinterpret_cast<float*>(ws);           ws += align_up((size_t)G * d->C * 4 * kImage * sizeof(float), 256);
-    void* dbg = ws;                                       ws += 512;
+    void* dbg = ws;                                       ws += 2048;
     float* ckpt = reinterpret_cast<float*>(ws);
     if (fwd_workspace) {
         // the forward call of the same step left the factorisation, the sweep table and the
@@ -958,7 +959,7 @@ size_t pde_adi_backward_step_workspace_bytes(const PdeAdiDesc* d, int32_t sweeps
     PdeAdiDesc ds;
     if (step_desc(d, sweeps_per_step, 0, ds) != PDE_OK || num_checkpoints < 0) return 0;
     const int G = groups_per_channel(&ds, kWaves * kJBwd, 8 / kWaves);
-    return align_up((size_t)G * d->C * 4 * kImage * sizeof(float), 256) + 512 +
+    return align_up((size_t)G * d->C * 4 * kImage * sizeof(float), 256) + 2048 +
            align_up((size_t)num_checkpoints * d->B * d->C * d->N * d->N * sizeof(float), 256);
 }
 
@@ -981,7 +982,7 @@ int pde_adi_backward_step(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t 
     const SweepTab* tab = reinterpret_cast<const SweepTab*>(fw + steps_tab_offset(d)) + step;
     char* ws = static_cast<char*>(workspace);
     float* part = reinterpret_cast<float*>(ws);           ws += align_up((size_t)G * d->C * 4 * kImage * sizeof(float), 256);
-    void* dbg = ws;                                       ws += 512;
+    void* dbg = ws;                                       ws += 2048;
     float* ckpt = reinterpret_cast<float*>(ws);
     return launch_bwd_sweeps(&ds, gy, y, u, ckpt_mask, nck, Sf, gu, coef, tab, varying, part, dbg, ckpt, G,
                              accumulate != 0, static_cast<hipStream_t>(stream));

@@ -13,7 +13,10 @@ namespace {
 #endif
 constexpr int kWaves = PDE_WAVES;                 // waves per workgroup
 constexpr int kThreads = kWaves * 64;
-constexpr int kRing = 3;                          // coefficient-record ring of the skewed kernels
+#ifndef PDE_RING
+#define PDE_RING 3
+#endif
+constexpr int kRing = PDE_RING;                   // coefficient-record ring of the skewed kernels (2 is enough without the skew)
 #ifndef PDE_SKEW
 #define PDE_SKEW 1
 #endif
@@ -117,11 +120,24 @@ __device__ __forceinline__ void lds_dma16_s(const float* sbase, unsigned voff, f
 __device__ __forceinline__ unsigned lds_byte_address(const float* lds_base) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const float*)lds_base;
 }
+// a pointer the compiler cannot prove wave-uniform, made so (the "s" operand of the DMA must be an SGPR pair)
+__device__ __forceinline__ const float* uniform_ptr(const float* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const float*)(((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ void lds_dma16_a(const float* sbase, unsigned voff, unsigned lds_bytes) {
     const unsigned lds = __builtin_amdgcn_readfirstlane(lds_bytes);
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(voff), "s"(sbase) : "memory");
 }
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Diagnostic builds only (tools/ablate.sh): PDE_ABL bit 0 = coefficient rows are read from LDS for the first item only,
+// bit 1 = no re-layouts, bit 2 = no plane loads/stores after the first chunk.  Results are WRONG; only the launch time
+// is read.  No shipped kernel is built with PDE_ABL != 0.
+#ifndef PDE_ABL
+#define PDE_ABL 0
+#endif
 
 #ifdef PDE_STAMP
 // Diagnostic build only (tools/stamp.sh): cycle stamps of one wave's phases inside a sweep.  The
@@ -186,12 +202,21 @@ __device__ __forceinline__ v4f v4_fma(v4f a, v4f b, v4f c) {
     return v4f{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w)};
 }
 #endif
+struct v3f { float x, y, z; };
+__device__ __forceinline__ v3f operator+(v3f a, v3f b) { return v3f{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ v3f operator-(v3f a, v3f b) { return v3f{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ v3f operator*(v3f a, v3f b) { return v3f{a.x * b.x, a.y * b.y, a.z * b.z}; }
+__device__ __forceinline__ v3f operator-(v3f a) { return v3f{-a.x, -a.y, -a.z}; }
 template <int J> struct Pack;
 template <> struct Pack<1> { using P = float; };
+template <> struct Pack<3> { using P = v3f; };
 template <> struct Pack<2> { using P = v2f; };
 template <> struct Pack<4> { using P = v4f; };        // forward only: four planes share every coefficient read
 template <int C> __device__ __forceinline__ float pk_get(float p) { return p; }
 template <int C> __device__ __forceinline__ float pk_get(v2f p) { return C ? p.y : p.x; }
+template <int C> __device__ __forceinline__ float pk_get(v3f p) { return C == 0 ? p.x : C == 1 ? p.y : p.z; }
+template <int C> __device__ __forceinline__ void pk_set(v3f& p, float v) { if (C == 0) p.x = v; else if (C == 1) p.y = v; else p.z = v; }
+__device__ __forceinline__ v3f pk_fma(v3f a, v3f b, v3f c) { return v3f{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z)}; }
 template <int C> __device__ __forceinline__ float pk_get(v4f p) { return C == 0 ? p.x : C == 1 ? p.y : C == 2 ? p.z : p.w; }
 template <int C> __device__ __forceinline__ void pk_set(float& p, float v) { p = v; }
 template <int C> __device__ __forceinline__ void pk_set(v2f& p, float v) { if (C) p.y = v; else p.x = v; }
@@ -205,11 +230,15 @@ template <class P> __device__ __forceinline__ P pk_bc(float s);
 template <> __device__ __forceinline__ float pk_bc<float>(float s) { return s; }
 template <> __device__ __forceinline__ v2f pk_bc<v2f>(float s) { return v2f{s, s}; }
 template <> __device__ __forceinline__ v4f pk_bc<v4f>(float s) { return v4f{s, s, s, s}; }
+template <> __device__ __forceinline__ v3f pk_bc<v3f>(float s) { return v3f{s, s, s}; }
 __device__ __forceinline__ float pk_hsum(float p) { return p; }
 __device__ __forceinline__ float pk_hsum(v2f p) { return p.x + p.y; }
+__device__ __forceinline__ float pk_hsum(v3f p) { return p.x + p.y + p.z; }
+__device__ __forceinline__ float pk_hsum(v4f p) { return (p.x + p.y) + (p.z + p.w); }
 // per-component map (cross-lane moves have no packed form)
 template <class F> __device__ __forceinline__ float pk_map(float p, F&& f) { return f(p); }
 template <class F> __device__ __forceinline__ v2f pk_map(v2f p, F&& f) { return v2f{f(p.x), f(p.y)}; }
+template <class F> __device__ __forceinline__ v3f pk_map(v3f p, F&& f) { return v3f{f(p.x), f(p.y), f(p.z)}; }
 template <class F> __device__ __forceinline__ v4f pk_map(v4f p, F&& f) { return v4f{f(p.x), f(p.y), f(p.z), f(p.w)}; }
 
 // Stage COUNT floats of a coefficient record global -> registers -> LDS: up to three 16-byte
@@ -543,12 +572,23 @@ __global__ __launch_bounds__(kThreads, (sizeof(IO) < 4 ? 4 : 1)) void adi_fwd_ke
     // LDS-DMA (no registers: a record staged through VGPRs costs a VMEM return and a ds_write per dword,
     // 15 % of everything this kernel moves through the register file).
     int cur = 0;                                          // ring slot of my current item
+    // Wave w brings pieces w, w + kWaves, ... of a record (whole 1-KB pieces: the padded window lies inside the global
+    // record, so no lane is masked).  Everything that does not depend on the sweep is computed once: a piece is one
+    // scalar multiply-add for the source, one add for m0 and the DMA itself (the address arithmetic used to be a fifth
+    // of this kernel's scalar instructions, and every instruction of any kind costs its wave an issue slot).
+    constexpr int PPRF = kRecFwdPad / 256;                // 1-KB pieces per record
+    static_assert(kG_Inv + kRecFwdPad <= kRecStride, "the padded forward window must stay inside the record");
+    const float* dma_src0 = uniform_ptr(a.coef + (size_t)c * kRecStride + kG_Inv + wave * 256);
+    const unsigned dma_step = (unsigned)a.C * kRecStride;             // floats between the records of two sweeps
+    const unsigned dma_lds0 = lds_byte_address(cbuf) + wave * 1024u;
+    const unsigned dma_voff = 16u * lane;
     auto dma_rec = [&](int slot, int s) __attribute__((always_inline)) {
-        constexpr int PPR = kRecFwdPad / 256;             // 1-KB pieces per record
-        const float* rec = a.coef + ((size_t)s * a.C + c) * kRecStride + kG_Inv;
-        for (int p = wave; p < PPR; p += kWaves) {
-            const int f = p * 64 + lane;                  // 16-byte index inside the record
-            if (f < kRecFwd / 4) lds_dma16_s(rec + p * 256, 16u * lane, cbuf + (size_t)slot * kRecFwdPad + p * 256);
+        const float* src = dma_src0 + (size_t)((unsigned)s * dma_step);
+        const unsigned dst = dma_lds0 + (unsigned)slot * (kRecFwdPad * 4u);
+#pragma unroll
+        for (int i = 0; i < (PPRF + kWaves - 1) / kWaves; ++i) {
+            if ((i + 1) * kWaves <= PPRF || wave + i * kWaves < PPRF)
+                lds_dma16_a(src + i * kWaves * 256, dma_voff, dst + i * kWaves * 1024u);
         }
     };
     if (resident) {
@@ -567,10 +607,16 @@ __global__ __launch_bounds__(kThreads, (sizeof(IO) < 4 ? 4 : 1)) void adi_fwd_ke
     // coefficient rows of the current sweep: the first x sweep of a Strang step keeps those of the previous step's last
     // one (same record, see SweepArgs::pair_x) instead of reading them from LDS again
     float ce[M], cinv[M], cjn = 0.f;
+    bool abl_loaded = false;
     for (int q = g; q < nchunk; q += a.G) {
         typename Pack<J>::P v[M];
-        if constexpr (J > 2) load_planes_seq<N, J, IO>(u, q, wave, lane, l, hf, a.B, a.C, c, T, v);   // 16, not 16*J, registers in flight
+        if (!((PDE_ABL & 4) && abl_loaded)) {
+#ifndef PDE_FWD_PAR_LOAD
+#define PDE_FWD_PAR_LOAD 0
+#endif
+        if constexpr (J > 2 && !PDE_FWD_PAR_LOAD) load_planes_seq<N, J, IO>(u, q, wave, lane, l, hf, a.B, a.C, c, T, v);   // 16, not 16*J, registers in flight
         else load_planes<N, J, IO>(u, q, wave, lane, l, hf, a.B, a.C, c, T, v);
+        }
         auto sweep = [&](auto AXC, int s, auto TWINC) {
             constexpr int AX = decltype(AXC)::value;
             int sp = s + lag + 1;                         // sweep of the item staged in this interval
@@ -578,18 +624,19 @@ __global__ __launch_bounds__(kThreads, (sizeof(IO) < 4 ? 4 : 1)) void adi_fwd_ke
             if (sp >= a.S) sp -= a.S;
             int ps = cur + lag + 1;
             if (ps >= kRing) ps -= kRing;
-            if (!resident) dma_rec(ps, sp);
+            if (!resident && !((PDE_ABL & 8) && abl_loaded)) dma_rec(ps, sp);
             const float* rec = cbuf + (resident ? s : cur) * kRecFwdPad;
             const int axs = (AX >= 0) ? AX : tab->axis[s];
-            if (axs == PDE_AXIS_Y) relayout_all<N, J>(v, T, l, hf);
-            if (!(decltype(TWINC)::value && a.pair_x != 0 && s != 0)) load_fwd_rows<M>(rec, l, hf, ce, cinv, cjn);
+            if (axs == PDE_AXIS_Y && !(PDE_ABL & 2)) relayout_all<N, J>(v, T, l, hf);
+            if (!(decltype(TWINC)::value && a.pair_x != 0 && s != 0) && !((PDE_ABL & 1) && abl_loaded)) load_fwd_rows<M>(rec, l, hf, ce, cinv, cjn);
+            abl_loaded = true;
             solve_fwd_rows<M, J>(v, ce, cinv, cjn, hf);
-            if (axs == PDE_AXIS_Y) relayout_all<N, J>(v, T, l, hf);
+            if (axs == PDE_AXIS_Y && !(PDE_ABL & 2)) relayout_all<N, J>(v, T, l, hf);
             if (a.ckpt != nullptr && ck_bit(a.ck, s)) {   // backward pre-pass: park this state (fp32)
                 float* slot = a.ckpt + (size_t)ck_slot(a.ck, s) * a.B * a.C * plane;
                 store_planes<N, J, float>(slot, q, wave, lane, l, hf, a.B, a.C, c, T, v);
             }
-            if (!resident) {
+            if (!resident && !((PDE_ABL & 8) && s > 0)) {
                 dma_wait_all();                           // my pieces of the next record have landed
                 __syncthreads();
                 cur = (cur == kRing - 1) ? 0 : cur + 1;
@@ -609,7 +656,7 @@ __global__ __launch_bounds__(kThreads, (sizeof(IO) < 4 ? 4 : 1)) void adi_fwd_ke
         } else {
             for (int s = 0; s < a.S; ++s) sweep(std::integral_constant<int, -1>{}, s, std::false_type{});
         }
-        if (y != nullptr) store_planes<N, J, IO>(y, q, wave, lane, l, hf, a.B, a.C, c, T, v);
+        if (y != nullptr && !((PDE_ABL & 4) && q + a.G < nchunk)) store_planes<N, J, IO>(y, q, wave, lane, l, hf, a.B, a.C, c, T, v);
     }
     if (!lag) __syncthreads();                            // the interval in which the upper waves finish
 }
@@ -640,6 +687,8 @@ __device__ __forceinline__ void solve_adj(typename Pack<J>::P (&r)[M], const flo
 // acc += sum over the planes of a lane of g*q (the accumulators are shared by the planes)
 __device__ __forceinline__ float acc_gq(float acc, float g, float q) { return fmaf(g, q, acc); }
 __device__ __forceinline__ float acc_gq(float acc, v2f g, v2f q) { return fmaf(g.y, q.y, fmaf(g.x, q.x, acc)); }
+__device__ __forceinline__ float acc_gq(float acc, v3f g, v3f q) { return fmaf(g.z, q.z, fmaf(g.y, q.y, fmaf(g.x, q.x, acc))); }
+__device__ __forceinline__ float acc_gq(float acc, v4f g, v4f q) { return fmaf(g.w, q.w, fmaf(g.z, q.z, fmaf(g.y, q.y, fmaf(g.x, q.x, acc)))); }
 
 // After an x sweep has been undone on the adjoint (g in r[]), use the sweep's OUTPUT state
 // x to (1) add g.(Lx) to the coefficient-gradient sums, (2) rebuild the sweep's input
@@ -692,6 +741,12 @@ __device__ __forceinline__ float lap_rows(float q, float xo, float nmu, float nm
 __device__ __forceinline__ v2f lap_rows(v2f q, v2f xo, float nmu, float nmd) {
     return v2f{lap_rows(q.x, xo.x, nmu, nmd), lap_rows(q.y, xo.y, nmu, nmd)};
 }
+__device__ __forceinline__ v3f lap_rows(v3f q, v3f xo, float nmu, float nmd) {
+    return v3f{lap_rows(q.x, xo.x, nmu, nmd), lap_rows(q.y, xo.y, nmu, nmd), lap_rows(q.z, xo.z, nmu, nmd)};
+}
+__device__ __forceinline__ v4f lap_rows(v4f q, v4f xo, float nmu, float nmd) {
+    return v4f{lap_rows(q.x, xo.x, nmu, nmd), lap_rows(q.y, xo.y, nmu, nmd), lap_rows(q.z, xo.z, nmu, nmd), lap_rows(q.w, xo.w, nmu, nmd)};
+}
 
 // Same for a y sweep, with the state (and g) in ROW layout: the second difference (and, when
 // MASKED, the transposed smoothing) runs across lanes (rows h-1, h+1 = lanes l-1, l+1 of the
@@ -736,13 +791,16 @@ __device__ __forceinline__ void state_y(const typename Pack<J>::P (&g)[N / 2], t
 // step pattern the records are staged by LDS-DMA (global_load_lds: no registers, no ds_write) into
 // a ring of kRing slots, one record per barrier interval, the upper waves running one sweep behind
 // the lower ones (phase skew, as in the forward kernel); records are padded to whole 1-KB DMA pieces.
+#ifndef PDE_BWD_ITEMB
+#define PDE_BWD_ITEMB 0     // 1: one barrier per sweep, two-slot ring, no phase skew (small LDS footprint: two workgroups per CU)
+#endif
 template <bool MASKED, int SPLIT>
 struct BwdStage {
     static constexpr int kSps = SPLIT == kSplitStrang ? 3 : (SPLIT == kSplitLie ? 2 : 1);
     static constexpr bool kStep = SPLIT != kSplitAny;
     static constexpr int kRec = MASKED ? kRecBwdMasked : kRecBwd;
     static constexpr int kRecPad = kStep ? ((kRec / 4 + 63) / 64) * 256 : kRec;
-    static constexpr int kSlots = 2 * kSps + 1;           // record ring of the pattern kernels
+    static constexpr int kSlots = PDE_BWD_ITEMB ? 2 : 2 * kSps + (PDE_SKEW ? 1 : 0);   // record ring of the pattern kernels
     static constexpr int kFloats = kStep ? kSlots * kRecPad : 2 * kRecPad;
 };
 
@@ -776,20 +834,35 @@ __device__ __forceinline__ void adi_bwd_body(const SweepArgs& a, int blk) {
     // per-axis table entries: scalar loads once, not a dependent chain of them in every sweep
     const int first_x = tab->first_s[0], first_y = tab->first_s[1];
     const float tlast_x = tab->t_last[0], tlast_y = tab->t_last[1];
+    // The per-sweep time increments live in the lanes of ONE register (lane s = sweep s) and are picked with v_readlane:
+    // a scalar load per item costs the wave its full memory latency (~550 cycles measured, a quarter of the run time of
+    // a build with everything else removed) because the compiler must wait for lgkmcnt(0) before the next LDS read.
+    const float dts_lanes = a.tab->dts[lane < PDE_MAX_SWEEPS ? lane : 0];
+    auto dts_of = [&](int s) __attribute__((always_inline)) -> float {
+        if (s < 64) return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dts_lanes), s));
+        return tab->dts[s];
+    };
 
     // one time step per launch (the per-step launches of the layers with a channel operator): its SPS records stay in
     // the ring for the whole launch and the waves run free of each other — see adi_fwd_kernel
     const bool resident = ST::kStep && a.S == SPS;
-    const int lag = (ST::kStep && !resident) ? wave_lag(wave) : 0;
+    const int lag = (ST::kStep && !resident && !PDE_BWD_ITEMB) ? wave_lag(wave) : 0;
     // (no young_half_priority here: measured 6 % slower in the backward, 4.5 % faster in the forward)
     // record of sweep s -> ring slot `slot`
+    // (whole 1-KB pieces, sweep-independent address parts computed once: see adi_fwd_kernel)
+    constexpr int PPR = RECP / 256;                       // 1-KB pieces per record
+    static_assert(!ST::kStep || kBwdOff + RECP <= kRecStride, "the padded backward window must stay inside the record");
+    const float* dma_src0 = uniform_ptr(a.coef + (size_t)c * kRecStride + kBwdOff + wave * 256);
+    const unsigned dma_step = (unsigned)a.C * kRecStride;
+    const unsigned dma_lds0 = lds_byte_address(cbuf) + wave * 1024u;
+    const unsigned dma_voff = 16u * lane;
     auto dma_rec = [&](int slot, int s) __attribute__((always_inline)) {
-        constexpr int PPR = RECP / 256;                   // 1-KB pieces per record
-        for (int p = wave; p < PPR; p += kWaves) {
-            const int f = p * 64 + lane;                  // 16-byte index inside the record
-            const float* src = a.coef + ((size_t)s * a.C + c) * kRecStride + kBwdOff + p * 256;   // wave-uniform
-            float* dst = cbuf + (size_t)slot * RECP + p * 256;                       // wave-uniform
-            if (f < REC / 4) lds_dma16_s(src, 16u * lane, dst);
+        const float* src = dma_src0 + (size_t)((unsigned)s * dma_step);
+        const unsigned dst = dma_lds0 + (unsigned)slot * (RECP * 4u);
+#pragma unroll
+        for (int i = 0; i < (PPR + kWaves - 1) / kWaves; ++i) {
+            if ((i + 1) * kWaves <= PPR || wave + i * kWaves < PPR)
+                lds_dma16_a(src + i * kWaves * 256, dma_voff, dst + i * kWaves * 1024u);
         }
     };
 
@@ -805,6 +878,12 @@ __device__ __forceinline__ void adi_bwd_body(const SweepArgs& a, int blk) {
     // LDS read returns costs the SIMD ~6 cycles (tools/ubench/simd_share.hip), the three rows of a sweep are 37 % of an
     // x sweep's time
     float ce[M], cinv[M], ckap[M], cjn = 0.f;
+    bool abl_loaded = false;
+#ifdef PDE_STAMP
+    // phase stamps of waves 0 and 4 of one workgroup during one barrier interval: [wave/4][item in step][phase] at dbg + 1024
+    bool stamp_on = false;
+    unsigned long long* stamps = nullptr;
+#endif
     auto body = [&](auto AXC, int axr, int s, const float* rec, float dts, auto TWINC) __attribute__((always_inline)) {
         constexpr int AX = decltype(AXC)::value;
         const int axs = (AX >= 0) ? AX : axr;
@@ -812,36 +891,53 @@ __device__ __forceinline__ void adi_bwd_body(const SweepArgs& a, int blk) {
         const float* crow = rec + l * kLineStride + hf * kHalfPad;
         // the newest sweep of my chunk has no twin before it (the previous item belongs to another chunk)
         const bool twin = decltype(TWINC)::value && a.pair_x != 0 && s != a.S - 1;
-        if (!twin) cjn = rec[kB_Jn + l];
+        const bool abl_skip = (PDE_ABL & 1) && abl_loaded;
+        abl_loaded = true;
+        if (!twin && !abl_skip) cjn = rec[kB_Jn + l];
+        PDE_STAMP_AT(0);
         if (axs == PDE_AXIS_Y) {
-            relayout_all<N, J>(r, T, l, hf);
-            load_half<M>(crow + kB_E, ce);
-            load_half<M>(crow + kB_Inv, cinv);
+            if (!(PDE_ABL & 2)) relayout_all<N, J>(r, T, l, hf);
+            PDE_STAMP_AT(1);
+            if (!abl_skip) {
+                load_half<M>(crow + kB_E, ce);
+                load_half<M>(crow + kB_Inv, cinv);
+            }
             solve_adj<M, J>(r, ce, cinv, cjn, hf);
-            relayout_all<N, J>(r, T, l, hf);
-            load_half<M>(crow + kB_KapX, ckap);
+            PDE_STAMP_AT(2);
+            if (!(PDE_ABL & 2)) relayout_all<N, J>(r, T, l, hf);
+            PDE_STAMP_AT(3);
+            if (!abl_skip) load_half<M>(crow + kB_KapX, ckap);
             state_y<N, J, MASKED>(r, x, Ay, ckap, rec, l, hf, a.smooth3);
-            if (dts != 0.f) {
+            PDE_STAMP_AT(4);
+            if (dts != 0.f && !(PDE_ABL & 16)) {
 #pragma unroll
                 for (int k = 0; k < M; ++k) Ty[k] = fmaf(dts, Ay[k], Ty[k]);
             }
         } else {
             // partner half's innermost state: issue the exchange now, use it after the solve
             const P xin = pk_map(x[M - 1], [&](float z) { return xchg_half(z, hf); });
-            if (!twin) {
+            if (!twin && !abl_skip) {
                 load_half<M>(crow + kB_E, ce);
                 load_half<M>(crow + kB_Inv, cinv);
             }
+            PDE_STAMP_AT(1);
             solve_adj<M, J>(r, ce, cinv, cjn, hf);
-            if (!twin) load_half<M>(crow + kB_KapX, ckap);
+            PDE_STAMP_AT(2);
+            if (!twin && !abl_skip) load_half<M>(crow + kB_KapX, ckap);
+            PDE_STAMP_AT(3);
             state_x<M, J, MASKED>(r, x, Ax, xin, ckap, rec, l, hf, a.smooth3);
-            if (dts != 0.f) {
+            PDE_STAMP_AT(4);
+            if (dts != 0.f && !(PDE_ABL & 16)) {
 #pragma unroll
                 for (int k = 0; k < M; ++k) Tx[k] = fmaf(dts, Ax[k], Tx[k]);
             }
         }
+        PDE_STAMP_AT(5);
         // x now holds the rebuilt state after sweep s-1; take the checkpoint instead if there is one
-        if (s > 0 && a.ckpt != nullptr && ck_bit(a.ck, s - 1)) {
+#ifndef PDE_NO_CKPT
+#define PDE_NO_CKPT 0
+#endif
+        if (!PDE_NO_CKPT && s > 0 && a.ckpt != nullptr && ck_bit(a.ck, s - 1)) {
             const float* slot = a.ckpt + (size_t)ck_slot(a.ck, s - 1) * a.B * a.C * plane;
             load_planes<N, J, float>(slot, q, wave, lane, l, hf, a.B, a.C, c, T, x);
             const float sc = tab->ysc[s - 1];             // true state -> rescaled state of sweep s-1
@@ -849,14 +945,42 @@ __device__ __forceinline__ void adi_bwd_body(const SweepArgs& a, int blk) {
             for (int k = 0; k < M; ++k) x[k] = x[k] * pk_bc<P>(sc);
         }
     };
+    // Plane traffic of a chunk.  All 2J planes of a chunk are fetched together (their destination registers are dead at that
+    // point): one memory round trip instead of 2J (-21 us of 345 on the 512x64x32x32 launch).
+    constexpr int PPI_ = kWaves * J;
+    auto fetch_J = [&](const IO* base, int qq, float4 (&raw)[J][Geo<N>::kLoads]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int b = qq * PPI_ + wave * J + j;
+            plane_fetch<N, IO>(base + ((size_t)b * a.C + c) * (size_t)(N * N), b < a.B, lane, raw[j]);
+        }
+    };
+    auto place_J = [&](const float4 (&raw)[J][Geo<N>::kLoads], P (&dst)[M]) __attribute__((always_inline)) {
+        sfor<0, J>([&](auto CC) __attribute__((always_inline)) {
+            plane_to_rows<N, decltype(CC)::value>(raw[decltype(CC)::value], T, lane, l, hf, dst);
+        });
+    };
     auto chunk_in = [&]() __attribute__((always_inline)) {
-        load_planes_seq<N, J, IO>(gy, q, wave, lane, l, hf, a.B, a.C, c, T, r);
-        load_planes_seq<N, J, IO>(yy, q, wave, lane, l, hf, a.B, a.C, c, T, x);
+        if ((PDE_ABL & 4) && abl_loaded) return;
+        float4 rg[J][Geo<N>::kLoads], ry[J][Geo<N>::kLoads];
+        fetch_J(gy, q, rg);
+        fetch_J(yy, q, ry);
+        place_J(rg, r);
+        place_J(ry, x);
     };
     auto chunk_out = [&]() __attribute__((always_inline)) {
+        if ((PDE_ABL & 4) && more) return;
 #pragma unroll
         for (int k = 0; k < M; ++k) r[k] = r[k] * pk_bc<P>(a.gu_scale);      // undo the (1+eps) carried per sweep
         store_planes<N, J, IO>(gu, q, wave, lane, l, hf, a.B, a.C, c, T, r);
+    };
+    // end of chunk q: store its result; the next chunk comes in at the top of its first item.
+    // (Requesting the next chunk's planes BEFORE the stores — into the registers of the dead state — or loading them right
+    // here was tried: hipcc then spills 110-190 registers of this kernel and the launch takes twice as long.)
+    auto chunk_turn = [&]() __attribute__((always_inline)) {
+        chunk_out();
+        q += a.G;
+        more = q + a.G < nchunk;
     };
 
     if constexpr (ST::kStep) {
@@ -880,7 +1004,13 @@ __device__ __forceinline__ void adi_bwd_body(const SweepArgs& a, int blk) {
                 dsw = (dsw == 0) ? a.S - 1 : dsw - 1;
             }
         };
-        dma_next();
+        auto dma_one = [&]() __attribute__((always_inline)) {
+            if (ditem < ntot) dma_rec(dslot, dsw);
+            ++ditem;
+            dslot = (dslot + 1 == kSlots) ? 0 : dslot + 1;
+            dsw = (dsw == 0) ? a.S - 1 : dsw - 1;
+        };
+        if (PDE_BWD_ITEMB) dma_one(); else dma_next();
         dma_wait_all();
         __syncthreads();
         // The two halves run the same loop with their own compile-time pattern (position of an item
@@ -891,32 +1021,39 @@ __device__ __forceinline__ void adi_bwd_body(const SweepArgs& a, int blk) {
             int item = -LAG, s = a.S - 1, slot = 0;       // my next item, its sweep, its ring slot
 #pragma unroll 1
             for (int t = 0; t < nint; ++t) {
-                if (!resident) dma_next();
+                if (!resident && !PDE_BWD_ITEMB && !((PDE_ABL & 8) && t > 1)) dma_next();
                 sfor<0, SPS>([&](auto IC) __attribute__((always_inline)) {
                     constexpr int pos = (decltype(IC)::value - LAG + SPS) % SPS;     // 0: newest sweep of a step
                     constexpr int AX = ((SPS - 1 - pos) == 1) ? PDE_AXIS_Y : PDE_AXIS_X;
                     if (item >= 0 && item < ntot) {
+#ifdef PDE_STAMP
+                        stamp_on = (blk == 5 && t == 13 && (wave == 0 || wave == 4) && lane == 0);
+                        stamps = reinterpret_cast<unsigned long long*>(a.dbg) + 128 + ((wave >> 2) * SPS + decltype(IC)::value) * 6;
+#endif
+                        if (PDE_BWD_ITEMB && !resident) dma_one();
                         if constexpr (pos == 0) {
                             if (s == a.S - 1) chunk_in();
                         }
                         // Strang, newest sweep of a step (an x sweep): its record equals that of the sweep processed just
                         // before it, the first x sweep of the next step
-                        body(std::integral_constant<int, AX>{}, AX, s, cbuf + (size_t)slot * RECP, tab->dts[s],
+                        body(std::integral_constant<int, AX>{}, AX, s, cbuf + (size_t)slot * RECP, dts_of(s),
                              std::bool_constant<(SPLIT == kSplitStrang && pos == 0 && !MASKED)>{});
                         if constexpr (pos == SPS - 1) {
                             if (s == 0) {
-                                chunk_out();
-                                q += a.G;
-                                more = q + a.G < nchunk;
+                                chunk_turn();
                                 s = a.S;
                             }
                         }
                         --s;
                         slot = (slot + 1 == (resident ? SPS : kSlots)) ? 0 : slot + 1;
+                        if (PDE_BWD_ITEMB && !resident) {
+                            dma_wait_all();
+                            __syncthreads();
+                        }
                     }
                     ++item;
                 });
-                if (resident) continue;                   // nothing staged, nothing shared: no wait, no barrier
+                if (resident || PDE_BWD_ITEMB || ((PDE_ABL & 8) && t > 1)) continue;   // nothing staged, nothing shared: no wait, no barrier
 #ifdef PDE_STAMP
                 // every wave of one workgroup, intervals 2 and 3: work done, DMA landed, barrier passed
                 const bool tl_on = (blk == 5 && (t == 2 || t == 3) && lane == 0);
@@ -981,11 +1118,16 @@ __device__ __forceinline__ void adi_bwd_body(const SweepArgs& a, int blk) {
 // pattern), blocks [C*G, 2*C*G) the MASKED body (per-sweep clamp masks, table-driven); a block whose
 // channel belongs to the other variant — decided on the device by the factor kernel — leaves at once.
 // (Two launches over the same grid cost ~6 us more: the second one's blocks all start, look, and exit.)
+#ifndef PDE_BWD_MINW
+#define PDE_BWD_MINW 1
+#endif
 template <int N, int J, typename IO, int SPLIT>
-__global__ __launch_bounds__(kThreads) void adi_bwd_kernel(SweepArgs a) {
+__global__ __launch_bounds__(kThreads, PDE_BWD_MINW) void adi_bwd_kernel(SweepArgs a) {
     const int nb = a.C * a.G;
     if ((int)blockIdx.x < nb) adi_bwd_body<N, J, IO, false, SPLIT>(a, (int)blockIdx.x);
+#ifndef PDE_BWD_NO_MASKED        // diagnostic builds: the fast body alone (its own register allocation)
     else adi_bwd_body<N, 1, IO, true, kSplitAny>(a, (int)blockIdx.x - nb);
+#endif
 }
 
 }  // namespace

@@ -7,8 +7,14 @@
 namespace pde {
 struct SweepArgsOpaque;          // = SweepArgs of pde_adi_dev.h, passed by pointer across units
 
-constexpr int kJFwd = 4;         // planes per lane in the forward kernel
-constexpr int kJBwd = 2;         // planes per lane in the backward kernel
+#ifndef PDE_JF
+#define PDE_JF 4
+#endif
+#ifndef PDE_JB
+#define PDE_JB 2
+#endif
+constexpr int kJFwd = PDE_JF;    // planes per lane in the forward kernel
+constexpr int kJBwd = PDE_JB;    // planes per lane in the backward kernel
 
 // return 0 on success, PDE_E_LAUNCH otherwise
 #define PDE_DECLARE_N(NN)                                                                              \
