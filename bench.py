@@ -101,8 +101,10 @@ def graph_replay_ms(layer, u, gy, reps):
 
 def cpu_baseline(C, N, steps, sample_B):
     """The oracle in reference-faithful mode (per-unknown Python loop of torch ops, autograd
-    backward — what the reference does) on this box's host cores, bounded sample: a 2-sample
-    probe sizes the timed sample so that it stays near 20 s whatever the host is."""
+    backward — what the reference does) on this box's host cores, on a FIXED sample of B = 32 of the
+    same workload: one forward+backward, seconds and thread count reported.  (Rounds 1-2
+    sized the sample from a probe; the faithful oracle's autograd graph then fell over a memory cliff
+    on some hosts and the figure moved 8x between rounds.)"""
     from oracle import pde_oracle as O
     try:
         cores = len(os.sched_getaffinity(0))
@@ -122,19 +124,13 @@ def cpu_baseline(C, N, steps, sample_B):
         O.value_and_grads(lambda a, p: O.adi_forward(a, p, spec), u, params, gy)
         return time.perf_counter() - t0
 
-    print("[bench] cpu_baseline probe ...", file=sys.stderr, flush=True)
-    probe = once(2)
-    nb = int(max(2, min(sample_B, 2 * 20.0 / max(probe, 1e-3))))
-    print(f"[bench] cpu_baseline probe {probe:.1f} s for 2 samples; timing {nb} samples", file=sys.stderr, flush=True)
+    nb = int(sample_B)
+    print(f"[bench] cpu_baseline: oracle, B={nb}, {cores} threads ...", file=sys.stderr, flush=True)
     dt = once(nb)
-    runs = [(nb, dt)]
-    if dt < 8.0 and nb < sample_B:              # batching made it cheaper than the probe said: aim at ~15 s
-        nb2 = int(min(sample_B, max(nb + 1, nb * 15.0 / max(dt, 1e-3))))
-        print(f"[bench] cpu_baseline {dt:.1f} s was short; timing {nb2} samples", file=sys.stderr, flush=True)
-        runs.append((nb2, once(nb2)))
-    nb, dt = max(runs, key=lambda r: r[0] / r[1])        # the CPU path at its best batch (large ones thrash its autograd graph)
+    print(f"[bench] cpu_baseline: {dt:.1f} s", file=sys.stderr, flush=True)
     out = {"value": nb / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
-           "sample": f"B={nb} of the same (C={C},{N}x{N},{steps} steps) workload, one fwd+bwd, "
+           "seconds": dt, "threads": cores,
+           "sample": f"fixed B={nb} of the same (C={C},{N}x{N},{steps} steps) workload, one fwd+bwd, "
                      f"oracle/pde_oracle.py in reference-faithful mode ({dt:.1f} s on {cores} threads)"}
     try:                                        # also: the C restatement with closed-form gradients (OpenMP)
         from oracle import c_oracle as CO
@@ -210,6 +206,18 @@ def config_legs(dev, rank, world, dist_on, quick):
         "SVHN.DiffusionLayer(32,128,num_steps=20) bf16 tensors, 60 sweeps + 20 couplings + skip, batch 512/GPU (BASELINE configs[3])")
     leg("cfg5", c5, (256, 64, 64, 64), torch.float32, 20, k,
         "tiny_imagenet.ImprovedDiffusionLayer(64,64) explicit 5-point step, batch 256/GPU (BASELINE configs[4])")
+    if rank == 0 and "cfg5" in legs:
+        # counter traffic of the two explicit kernels (separate FETCH_SIZE / WRITE_SIZE passes, profiles/pmc_traffic.json)
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                pj = json.load(f)
+            if "explicit5_fwd_wave_bytes_per_launch" in pj:
+                legs["cfg5"]["traffic"] = {"explicit5_fwd_wave": pj["explicit5_fwd_wave_bytes_per_launch"],
+                                           "explicit5_bwd_wave": pj["explicit5_bwd_wave_bytes_per_launch"],
+                                           "algorithmic": {"forward": 256 * 64 * 64 * 64 * 8, "backward": 256 * 64 * 64 * 64 * 12},
+                                           "taken_at_commit": pj.get("commit"), "unit": "bytes per launch"}
+        except (OSError, ValueError):
+            pass
 
     # the reference's OWN shapes (C = 3): cifar10.MultiScaleExtractor's three PDE layers on one 128-sample batch,
     # one launch per pass; host-launch-bound, reported as time per forward+backward
@@ -285,7 +293,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the per-config legs (cfg1, cfg3, cfg4, cfg5)")
-    ap.add_argument("--cpu-sample", type=int, default=160, help="upper bound of the CPU baseline sample (samples)")
+    ap.add_argument("--cpu-sample", type=int, default=32, help="samples of the CPU baseline (SURVEY §8d: fixed B = 32)")
     ap.add_argument("--rehearse-one-device", action="store_true",
                     help="developer rehearsal of the multi-rank path on a ONE-GPU box: every rank uses cuda:0 and the "
                          "collectives run over gloo (RCCL refuses two ranks on one device); timings are meaningless")
@@ -325,6 +333,10 @@ def main():
 
     import cnn_with_pde_amd as P
     B, C, N, steps = a.batch, a.channels, a.size, a.num_steps
+    # the CPU path first, before the GPU legs hold host memory (fixed B = 32)
+    cpu_base = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu_base = cpu_baseline(C, N, steps, a.cpu_sample)
     g = torch.Generator().manual_seed(1234 + rank)
     u = torch.randn(B, C, N, N, generator=g).to(dev).requires_grad_(True)
     gy = torch.randn(B, C, N, N, generator=g).to(dev)
@@ -421,6 +433,19 @@ def main():
                                  "adi_fwd_kernel": {"floor_ms_simd_rate": sf, "frac_simd_rate": sf / fwd_ms,
                                                     "floor_ms_per_wave_limit": wf, "frac_per_wave_limit": wf / fwd_ms}}
 
+    if dist_on:
+        # strong scaling beside the weak line: the SAME global batch of `--batch` samples split over the ranks
+        lo, hi = P.shard_range(B, rank, world)
+        us = u.detach()[: hi - lo].clone().requires_grad_(True)
+        gs = gy[: hi - lo].clone()
+        dts = timed(layer, us, gs, a.steps, a.warmup, dist_on, flat)
+        if rank == 0:
+            out["strong"] = {"scaling": "strong", "global_batch": B, "per_gpu_batch": hi - lo, "ms_per_step": dts / a.steps * 1e3,
+                             "value": B * a.steps / dts / 1e6, "unit": "Msamples/s",
+                             "note": "same layer, the global batch fixed at --batch and sharded over the ranks (contiguous "
+                                     "shards, gradient all-reduce every step); `value` above is the weak-scaling line"}
+        del us, gs
+
     if not a.no_secondary:
         layer2 = build_layer(C, N, steps, dev, rank, mixing=True)
         flat2 = P.GradBucket(layer2.parameters()) if dist_on else None
@@ -443,8 +468,8 @@ def main():
             out["configs"] = legs
 
     if rank == 0:
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(C, N, steps, a.cpu_sample)
+        if cpu_base is not None:
+            out["cpu_baseline"] = cpu_base
         print(json.dumps(out))
     if dist_on:
         import torch.distributed as dist

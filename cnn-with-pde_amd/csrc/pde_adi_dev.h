@@ -507,6 +507,23 @@ __device__ __forceinline__ void load_planes(const IO* base, int q, int wave, int
     });
 }
 
+// two planes at a time: half the memory round trips of load_planes_seq with 32 registers in flight
+template <int N, int J, typename IO>
+__device__ __forceinline__ void load_planes_pairs(const IO* base, int q, int wave, int lane, int l, int hf, int B, int C,
+                                                  int c, float* T, typename Pack<J>::P (&v)[N / 2]) {
+    static_assert(J % 2 == 0, "pairs");
+    constexpr int PPI = kWaves * J;
+    sfor<0, J / 2>([&](auto PC) __attribute__((always_inline)) {
+        constexpr int j0 = 2 * decltype(PC)::value;
+        float4 raw0[Geo<N>::kLoads], raw1[Geo<N>::kLoads];
+        const int b = q * PPI + wave * J + j0;
+        plane_fetch<N, IO>(base + ((size_t)b * C + c) * (size_t)(N * N), b < B, lane, raw0);
+        plane_fetch<N, IO>(base + ((size_t)(b + 1) * C + c) * (size_t)(N * N), b + 1 < B, lane, raw1);
+        plane_to_rows<N, j0>(raw0, T, lane, l, hf, v);
+        plane_to_rows<N, j0 + 1>(raw1, T, lane, l, hf, v);
+    });
+}
+
 // one plane at a time (fewer registers in flight; used where the caller's own state is large)
 template <int N, int J, typename IO>
 __device__ __forceinline__ void load_planes_seq(const IO* base, int q, int wave, int lane, int l, int hf, int B, int C,
@@ -537,7 +554,7 @@ __device__ __forceinline__ void store_planes(IO* base, int q, int wave, int lane
 // step, no per-sweep axis branch); kSplitAny reads the axis of every sweep from the table.
 // (second bound: waves per SIMD.  4 = two workgroups per CU; the bf16 instantiation otherwise takes 138 VGPRs and runs alone on its CU)
 template <int N, int J, typename IO, int SPLIT>
-__global__ __launch_bounds__(kThreads, (sizeof(IO) < 4 ? 4 : 1)) void adi_fwd_kernel(SweepArgs a) {
+__global__ __launch_bounds__(kThreads, (kWaves == 8 ? 4 : 1)) void adi_fwd_kernel(SweepArgs a) {
     constexpr int M = Geo<N>::M;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* cbuf = smem;                                   // [kRing][kRecFwdPad]
@@ -614,7 +631,8 @@ __global__ __launch_bounds__(kThreads, (sizeof(IO) < 4 ? 4 : 1)) void adi_fwd_ke
 #ifndef PDE_FWD_PAR_LOAD
 #define PDE_FWD_PAR_LOAD 0
 #endif
-        if constexpr (J > 2 && !PDE_FWD_PAR_LOAD) load_planes_seq<N, J, IO>(u, q, wave, lane, l, hf, a.B, a.C, c, T, v);   // 16, not 16*J, registers in flight
+        if constexpr (J > 2 && PDE_FWD_PAR_LOAD == 2) load_planes_pairs<N, J, IO>(u, q, wave, lane, l, hf, a.B, a.C, c, T, v);
+        else if constexpr (J > 2 && !PDE_FWD_PAR_LOAD) load_planes_seq<N, J, IO>(u, q, wave, lane, l, hf, a.B, a.C, c, T, v);   // 16, not 16*J, registers in flight
         else load_planes<N, J, IO>(u, q, wave, lane, l, hf, a.B, a.C, c, T, v);
         }
         auto sweep = [&](auto AXC, int s, auto TWINC) {
@@ -787,6 +805,63 @@ __device__ __forceinline__ void state_y(const typename Pack<J>::P (&g)[N / 2], t
     }
 }
 
+// The same as state_y (fast body only: clamp masks applied after the sum over sweeps), with the neighbour ROWS fetched
+// through the wave's private LDS image instead of DPP.  On gfx950 a DPP instruction holds the VALU for two issue slots
+// and costs its wave ~18 cycles beside a partner wave (tools/ubench/valu_issue, real_stream: the y sweep's VALU stream
+// with its 64 v_fmac_f32_dpp takes 1957 cycles per wave at two waves per SIMD, the x sweep's 180 plain instructions
+// 800): a lane writes its half row (4 x ds_write_b128) and reads the half rows above and below (8 x ds_read_b128),
+// then the second difference is three plain VOP2 instructions per element.
+#ifndef PDE_YLDS
+#define PDE_YLDS 0          // measured: 363 us against 327 with DPP (and 14 spilled registers)
+#endif
+template <int N, int J>
+__device__ __forceinline__ void state_y_lds(const typename Pack<J>::P (&g)[N / 2], typename Pack<J>::P (&x)[N / 2],
+                                            float (&acc)[N / 2], const float (&kap)[N / 2], float* T, int l, int hf) {
+    constexpr int M = N / 2;
+    const bool edge = (l == 0 || l == N - 1);
+    const float kk = edge ? 1.0f : 2.0f;
+    const float nmu = (l > 0) ? -1.0f : 0.0f;            // row above exists
+    const float nmd = (l < N - 1) ? -1.0f : 0.0f;        // row below exists
+    const int lu = (l > 0 && l < N) ? l - 1 : l, ld = (l < N - 1) ? l + 1 : l;   // (a missing neighbour reads my own row, times 0)
+    float* mine = T + l * kLineStride + hf * kHalfPad;
+    const float* up = T + lu * kLineStride + hf * kHalfPad;
+    const float* dn = T + ld * kLineStride + hf * kHalfPad;
+    sfor<0, J>([&](auto CC) __attribute__((always_inline)) {
+        constexpr int C = decltype(CC)::value;
+        if (l < N) {
+#pragma unroll
+            for (int i = 0; i < (M + 3) / 4; ++i) {
+                float4 v;
+                v.x = pk_get<C>(x[4 * i]);
+                v.y = (4 * i + 1 < M) ? pk_get<C>(x[4 * i + 1]) : 0.f;
+                v.z = (4 * i + 2 < M) ? pk_get<C>(x[4 * i + 2]) : 0.f;
+                v.w = (4 * i + 3 < M) ? pk_get<C>(x[4 * i + 3]) : 0.f;
+                *reinterpret_cast<float4*>(mine + 4 * i) = v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // four elements at a time: 8 registers of neighbour values in flight, not 32
+        sfor<0, (M + 3) / 4>([&](auto IC) __attribute__((always_inline)) {
+            constexpr int i = decltype(IC)::value;
+            const float4 u4 = *reinterpret_cast<const float4*>(up + 4 * i);
+            const float4 d4 = *reinterpret_cast<const float4*>(dn + 4 * i);
+            const float xu[4] = {u4.x, u4.y, u4.z, u4.w}, xd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                constexpr int dummy = 0; (void)dummy;
+                const int k = 4 * i + j;
+                if (k < M) {
+                    const float xo = pk_get<C>(x[k]);
+                    const float q = fmaf(nmd, xd[j], fmaf(nmu, xu[j], kk * xo));
+                    acc[k] = fmaf(pk_get<C>(g[k]), q, acc[k]);
+                    pk_set<C>(x[k], fmaf(kap[k], q, xo));
+                }
+            }
+        });
+        __builtin_amdgcn_wave_barrier();
+    });
+}
+
 // LDS footprint (floats) of the coefficient buffers of the backward kernel.  With a compile-time
 // step pattern the records are staged by LDS-DMA (global_load_lds: no registers, no ds_write) into
 // a ring of kRing slots, one record per barrier interval, the upper waves running one sweep behind
@@ -907,7 +982,8 @@ __device__ __forceinline__ void adi_bwd_body(const SweepArgs& a, int blk) {
             if (!(PDE_ABL & 2)) relayout_all<N, J>(r, T, l, hf);
             PDE_STAMP_AT(3);
             if (!abl_skip) load_half<M>(crow + kB_KapX, ckap);
-            state_y<N, J, MASKED>(r, x, Ay, ckap, rec, l, hf, a.smooth3);
+            if constexpr (!MASKED && PDE_YLDS) state_y_lds<N, J>(r, x, Ay, ckap, T, l, hf);
+            else state_y<N, J, MASKED>(r, x, Ay, ckap, rec, l, hf, a.smooth3);
             PDE_STAMP_AT(4);
             if (dts != 0.f && !(PDE_ABL & 16)) {
 #pragma unroll
