@@ -219,6 +219,48 @@ def config_legs(dev, rank, world, dist_on, quick):
         except (OSError, ValueError):
             pass
 
+    # one application of cifar_2version.SymmetricLayer at the reference's own size (3 x 32 x 32: K is 3072^2)
+    # and batch (128), forward + backward, on the fp32 matrix cores (pde_rh.hip); the same module in plain torch (rocBLAS)
+    # beside it.  MFMA-bound: 6 products of 2*B*D^2 flop (2 forward, 4 backward).
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            sl = P.SymmetricLayer(3, 32).to(dev).train()
+        g = torch.Generator().manual_seed(77 + rank)
+        xs = torch.randn(128, 3, 32, 32, generator=g).to(dev).requires_grad_(True)
+        gs = torch.randn(128, 3, 32, 32, generator=g).to(dev)
+
+        def sl_ms(fused, reps):
+            sl.fused = fused
+            def one():
+                for p_ in sl.parameters():
+                    p_.grad = None
+                xs.grad = None
+                sl(xs).backward(gs)
+            for _ in range(5):
+                one()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                one()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / reps * 1e3
+        ms_f, ms_t = sl_ms(True, 2 * k), sl_ms(False, 2 * k)
+        flop = 6 * 2.0 * 128 * 3072 * 3072
+        if rank == 0:
+            legs["rh_symmetric"] = {"workload": "cifar_2version.SymmetricLayer(3, 32): -act(BN(Y K^T)) K, K 3072 x 3072 fp32, batch 128, "
+                                                "training mode, forward + backward (cifar_2version.py:190-220)",
+                                    "ms_per_step": ms_f, "ms_per_step_plain_torch_rocblas": ms_t, "value": 128 / ms_f / 1e3,
+                                    "unit": "Msamples/s", "dtype": "f32",
+                                    "roofline": {"bound": "mfma", "achieved": flop / (ms_f * 1e-3) / 1e12, "peak": 157.3,
+                                                 "unit": "TFLOP/s", "frac": flop / (ms_f * 1e-3) / 1e12 / 157.3,
+                                                 "flop_per_step": flop,
+                                                 "note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32) peak, MI355X_MICROARCH.md; whole "
+                                                         "step incl. launches and the autograd path"}}
+        del sl, xs, gs
+    except Exception as e:                                   # reported, never fatal for the bench line
+        if rank == 0:
+            legs["rh_symmetric"] = {"error": repr(e)[:200]}
+
     # the reference's OWN shapes (C = 3): cifar10.MultiScaleExtractor's three PDE layers on one 128-sample batch,
     # one launch per pass; host-launch-bound, reported as time per forward+backward
     with contextlib.redirect_stdout(io.StringIO()):

@@ -1,0 +1,421 @@
+// The Ruthotto-Haber "symmetric layer" of cifar_2version.py:190-220 on the fp32 matrix cores of gfx950:
+//
+//     F_sym(Y) = -act(BN(Y K^T)) K            Y: (B, D) flattened image batch, K: (D, D) dense, D = C*H*W (3072)
+//
+// and the residual steps built on it (ParabolicBlock :223-236, HamiltonianBlock :239-258), which all have the form
+// out = base + scale * (act(BN(X K^T)) K).  Three kernels, all v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains, the fp32
+// vector rate, VALU left free for the epilogues):
+//
+//   strip kernel, NT  P = X K^T for ALL batch rows and a strip of 32 output features per workgroup, so the BatchNorm1d
+//                     statistics of a feature (over the batch) are workgroup-local and normalisation + activation are
+//                     the epilogue of the product (forward); in the backward the same product shape carries
+//                     dH = dF K^T with the activation derivative and the BatchNorm backward (two per-feature sums)
+//                     as epilogue;
+//   strip kernel, NN  out = base + scale * (H K): the residual update as epilogue (forward), dX = dP K (backward);
+//   outer kernel      dK = dP^T X + s * H^T dF: both uses of K in one pass over the (D, D) gradient (contraction over
+//                     the batch: the output write, 37.7 MB for D = 3072, is what bounds it).
+//
+// Boundary: plain pointers, caller-owned buffers, asynchronous on the given stream (include/pdecnn.h).
+#include "pde_common.h"
+
+namespace pde {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kRhThreads = 256;          // 4 waves, one per SIMD
+constexpr int kRhBK = 16;                // contraction slab
+constexpr int kRhLdA = 18;               // LDS row stride of a [rows][16] slab: ds_read_b64 by 32 rows hits 32 distinct bank pairs
+constexpr int kRhLdN = 32;               // LDS row stride of a [16][32] slab (NN operand)
+constexpr int kRhMaxB = 512;             // batch rows a strip workgroup can hold (4 row blocks of 32 per wave)
+
+enum { kActIdentity = 0, kActRelu = 1, kActTanh = 2 };
+
+// ---- strip product: acc[b][j] = sum_k X[b][k] * Wop[k][j] for every batch row (padded to a multiple of 32) ----
+//   NT: Wop[k][j] = W[(n0 + j) * ldw + k]        NN: Wop[k][j] = W[k * ldw + n0 + j]
+// Wave w owns the row blocks w, w + 4, ... (RBW of them).  Contraction order inside a slab of 16: MFMA step 2t takes
+// k = 4t + 2*kh, step 2t + 1 takes k = 4t + 2*kh + 1 (kh = lane >> 5) — one 8-byte LDS read feeds two steps.
+template <int RBW, bool NT>
+__device__ __forceinline__ void strip_gemm(const float* __restrict__ X, int B, int Kdim, int ldx, const float* __restrict__ W,
+                                           int ldw, int n0, f32x16 (&acc)[RBW], float* As, float* Ws) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int jj = lane & 31, kh = lane >> 5;
+    constexpr int RB = 4 * RBW;                           // row blocks held by the workgroup
+    constexpr int AF4 = RB * 32 * kRhBK / 4;              // float4 of an X slab
+    constexpr int APT = AF4 / kRhThreads;                 // per thread (RBW * 2)
+#pragma unroll
+    for (int m = 0; m < RBW; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+
+    float4 pa[APT], pw;
+    auto fetch = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < APT; ++m) {
+            const int f = tid + kRhThreads * m, row = f >> 2, c4 = f & 3;
+            pa[m] = (row < B) ? *reinterpret_cast<const float4*>(X + (size_t)row * ldx + k0 + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (tid < 128) {
+            if (NT) {
+                const int row = tid >> 2, c4 = tid & 3;   // feature n0 + row, k0 + 4 c4
+                pw = *reinterpret_cast<const float4*>(W + (size_t)(n0 + row) * ldw + k0 + 4 * c4);
+            } else {
+                const int row = tid >> 3, c4 = tid & 7;   // k0 + row, features n0 + 4 c4
+                pw = *reinterpret_cast<const float4*>(W + (size_t)(k0 + row) * ldw + n0 + 4 * c4);
+            }
+        }
+    };
+    auto stage = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < APT; ++m) {
+            const int f = tid + kRhThreads * m, row = f >> 2, c4 = f & 3;
+            float* d = As + row * kRhLdA + 4 * c4;
+            *reinterpret_cast<float2*>(d) = make_float2(pa[m].x, pa[m].y);
+            *reinterpret_cast<float2*>(d + 2) = make_float2(pa[m].z, pa[m].w);
+        }
+        if (tid < 128) {
+            if (NT) {
+                const int row = tid >> 2, c4 = tid & 3;
+                float* d = Ws + row * kRhLdA + 4 * c4;
+                *reinterpret_cast<float2*>(d) = make_float2(pw.x, pw.y);
+                *reinterpret_cast<float2*>(d + 2) = make_float2(pw.z, pw.w);
+            } else {
+                const int row = tid >> 3, c4 = tid & 7;
+                *reinterpret_cast<float4*>(Ws + row * kRhLdN + 4 * c4) = pw;
+            }
+        }
+    };
+    fetch(0);
+    stage();
+    __syncthreads();
+    for (int k0 = 0; k0 < Kdim; k0 += kRhBK) {
+        const bool more = k0 + kRhBK < Kdim;
+        if (more) fetch(k0 + kRhBK);
+#pragma unroll
+        for (int t = 0; t < kRhBK / 4; ++t) {
+            float b0, b1;
+            if (NT) {
+                const float2 bv = *reinterpret_cast<const float2*>(Ws + jj * kRhLdA + 4 * t + 2 * kh);
+                b0 = bv.x; b1 = bv.y;
+            } else {
+                b0 = Ws[(4 * t + 2 * kh) * kRhLdN + jj];
+                b1 = Ws[(4 * t + 2 * kh + 1) * kRhLdN + jj];
+            }
+#pragma unroll
+            for (int m = 0; m < RBW; ++m) {
+                const int rb = wave + 4 * m;
+                const float2 av = *reinterpret_cast<const float2*>(As + (rb * 32 + jj) * kRhLdA + 4 * t + 2 * kh);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1, acc[m], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        if (more) {
+            stage();
+            __syncthreads();
+        }
+    }
+}
+
+// row of accumulator register r of row block rb for this lane (column = n0 + (lane & 31))
+__device__ __forceinline__ int acc_row(int rb, int r, int kh) { return rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh; }
+
+// sum over the whole workgroup of a per-lane value that belongs to column (lane & 31): every lane gets its column's total
+__device__ __forceinline__ float column_total(float v, float* red) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, jj = lane & 31;
+    __syncthreads();                                      // `red` may still be read from the previous call
+    red[wave * 64 + lane] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) s += red[w * 64 + jj] + red[w * 64 + 32 + jj];     // fixed order: deterministic
+    return s;
+}
+
+__device__ __forceinline__ float act_fwd(float x, int act) {
+    return act == kActRelu ? fmaxf(x, 0.f) : (act == kActTanh ? tanhf(x) : x);
+}
+// derivative written in terms of the activation's OUTPUT h
+__device__ __forceinline__ float act_bwd(float h, int act) {
+    return act == kActRelu ? (h > 0.f ? 1.f : 0.f) : (act == kActTanh ? 1.f - h * h : 1.f);
+}
+
+struct RhFwdArgs {
+    const float* X; const float* K; const float* gamma; const float* beta;
+    float* run_mean; float* run_var;
+    float* P; float* H; float* mean; float* invstd;
+    int B, D, act, training;
+    float momentum, eps;
+};
+
+// P = X K^T, BatchNorm1d over the batch (cifar_2version.py:201, 214-215), activation (:216)
+template <int RBW>
+__global__ __launch_bounds__(kRhThreads) void rh_fwd_strip_kernel(RhFwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float As[4 * RBW * 32 * kRhLdA];
+    __shared__ __attribute__((aligned(16))) float Ws[32 * kRhLdA];
+    __shared__ float red[4 * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, jj = lane & 31, kh = lane >> 5;
+    const int n0 = blockIdx.x * 32, col = n0 + jj;
+    f32x16 acc[RBW];
+    strip_gemm<RBW, true>(a.X, a.B, a.D, a.D, a.K, a.D, n0, acc, As, Ws);
+
+    float mu, istd;
+    if (a.training) {
+        float s = 0.f;
+#pragma unroll
+        for (int m = 0; m < RBW; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += acc[m][r];  // padded rows hold exact zeros
+        mu = column_total(s, red) / (float)a.B;
+        float q = 0.f;
+#pragma unroll
+        for (int m = 0; m < RBW; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float dlt = acc[m][r] - mu;
+                if (acc_row(wave + 4 * m, r, kh) < a.B) q = fmaf(dlt, dlt, q);
+            }
+        const float var = column_total(q, red) / (float)a.B;             // biased, as BatchNorm normalises
+        istd = 1.0f / sqrtf(var + a.eps);
+        if (threadIdx.x < 32 && a.run_mean != nullptr) {                  // running statistics (unbiased variance)
+            const float unb = a.B > 1 ? var * (float)a.B / (float)(a.B - 1) : var;
+            a.run_mean[col] = (1.f - a.momentum) * a.run_mean[col] + a.momentum * mu;
+            a.run_var[col] = (1.f - a.momentum) * a.run_var[col] + a.momentum * unb;
+        }
+    } else {
+        mu = a.run_mean[col];
+        istd = 1.0f / sqrtf(a.run_var[col] + a.eps);
+    }
+    if (threadIdx.x < 32) { a.mean[col] = mu; a.invstd[col] = istd; }
+    const float g = a.gamma[col], bt = a.beta[col];
+#pragma unroll
+    for (int m = 0; m < RBW; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = acc_row(wave + 4 * m, r, kh);
+            if (row < a.B) {
+                const float p = acc[m][r];
+                const float hn = fmaf((p - mu) * istd, g, bt);
+                a.P[(size_t)row * a.D + col] = p;
+                a.H[(size_t)row * a.D + col] = act_fwd(hn, a.act);
+            }
+        }
+}
+
+struct RhAxpyArgs {
+    const float* X; const float* K; const float* base; float* out;
+    int B, D;
+    float scale;
+};
+
+// out = base + scale * (X K)     (cifar_2version.py:217 and the residual updates :234, :254-255; backward: dX = dP K)
+template <int RBW>
+__global__ __launch_bounds__(kRhThreads) void rh_axpy_strip_kernel(RhAxpyArgs a) {
+    __shared__ __attribute__((aligned(16))) float As[4 * RBW * 32 * kRhLdA];
+    __shared__ __attribute__((aligned(16))) float Ws[kRhBK * kRhLdN];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, jj = lane & 31, kh = lane >> 5;
+    const int n0 = blockIdx.x * 32, col = n0 + jj;
+    f32x16 acc[RBW];
+    strip_gemm<RBW, false>(a.X, a.B, a.D, a.D, a.K, a.D, n0, acc, As, Ws);
+#pragma unroll
+    for (int m = 0; m < RBW; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = acc_row(wave + 4 * m, r, kh);
+            if (row < a.B) {
+                const size_t o = (size_t)row * a.D + col;
+                a.out[o] = a.base != nullptr ? fmaf(a.scale, acc[m][r], a.base[o]) : a.scale * acc[m][r];
+            }
+        }
+}
+
+struct RhBwdArgs {
+    const float* G; const float* K; const float* gamma;
+    const float* P; const float* H; const float* mean; const float* invstd;
+    float* dP; float* g_gamma; float* g_beta;
+    int B, D, act, training;
+    float scale;
+};
+
+// dH = scale * (G K^T); through the activation and the BatchNorm (training: batch statistics take part) -> dP, dgamma, dbeta
+template <int RBW>
+__global__ __launch_bounds__(kRhThreads) void rh_bwd_strip_kernel(RhBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float As[4 * RBW * 32 * kRhLdA];
+    __shared__ __attribute__((aligned(16))) float Ws[32 * kRhLdA];
+    __shared__ float red[4 * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, jj = lane & 31, kh = lane >> 5;
+    const int n0 = blockIdx.x * 32, col = n0 + jj;
+    f32x16 acc[RBW];
+    strip_gemm<RBW, true>(a.G, a.B, a.D, a.D, a.K, a.D, n0, acc, As, Ws);
+    const float mu = a.mean[col], istd = a.invstd[col], g = a.gamma[col];
+    float sb = 0.f, sg = 0.f;
+    f32x16 xh[RBW];
+#pragma unroll
+    for (int m = 0; m < RBW; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = acc_row(wave + 4 * m, r, kh);
+            float dhn = 0.f, xhat = 0.f;
+            if (row < a.B) {
+                const size_t o = (size_t)row * a.D + col;
+                dhn = a.scale * acc[m][r] * act_bwd(a.H[o], a.act);
+                xhat = (a.P[o] - mu) * istd;
+            }
+            acc[m][r] = dhn;
+            xh[m][r] = xhat;
+            sb += dhn;
+            sg = fmaf(dhn, xhat, sg);
+        }
+    const float dbeta = column_total(sb, red);
+    const float dgamma = column_total(sg, red);
+    if (threadIdx.x < 32) { a.g_beta[col] = dbeta; a.g_gamma[col] = dgamma; }
+    const float inv_b = 1.0f / (float)a.B;
+#pragma unroll
+    for (int m = 0; m < RBW; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = acc_row(wave + 4 * m, r, kh);
+            if (row < a.B) {
+                const float dhn = acc[m][r];
+                const float dp = a.training ? g * istd * (dhn - (dbeta + xh[m][r] * dgamma) * inv_b) : g * istd * dhn;
+                a.dP[(size_t)row * a.D + col] = dp;
+            }
+        }
+}
+
+struct RhOuterArgs {
+    const float* A1; const float* B1; const float* A2; const float* B2;
+    float* out;
+    int B, D;
+    float s2;
+};
+
+// out[i][j] = sum_b A1[b][i] B1[b][j] + s2 * sum_b A2[b][i] B2[b][j]: the gradient of K from both of its uses
+// (dP^T X from the first product, H^T dF from the second).  128 x 128 tile per workgroup, wave (wi, wj) a 64 x 64 quarter.
+__global__ __launch_bounds__(kRhThreads) void rh_outer_kernel(RhOuterArgs a) {
+    constexpr int BKB = 8, LD = 128 + 4;
+    __shared__ __attribute__((aligned(16))) float Sa[BKB * LD];
+    __shared__ __attribute__((aligned(16))) float Sb[BKB * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, jj = lane & 31, kh = lane >> 5;
+    const int i0 = blockIdx.y * 128, j0 = blockIdx.x * 128;
+    const int wi = wave >> 1, wj = wave & 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][q][r] = 0.f;
+    const int Bp = (a.B + BKB - 1) / BKB * BKB;
+    const int row = tid >> 5, c4 = tid & 31;              // slab row (batch sample), float4 column
+    float4 pa, pb;
+    auto fetch = [&](int v) __attribute__((always_inline)) {          // v: virtual batch row of the slab's first row
+        const bool second = v >= Bp;
+        const int b = (second ? v - Bp : v) + row;
+        const float* A = second ? a.A2 : a.A1;
+        const float* Bm = second ? a.B2 : a.B1;
+        pa = pb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (b < a.B) {                                    // (D is a multiple of 32: a float4 never straddles the edge)
+            if (i0 + 4 * c4 < a.D) pa = *reinterpret_cast<const float4*>(A + (size_t)b * a.D + i0 + 4 * c4);
+            if (j0 + 4 * c4 < a.D) pb = *reinterpret_cast<const float4*>(Bm + (size_t)b * a.D + j0 + 4 * c4);
+            if (second) { pb.x *= a.s2; pb.y *= a.s2; pb.z *= a.s2; pb.w *= a.s2; }
+        }
+    };
+    auto stage = [&]() __attribute__((always_inline)) {
+        *reinterpret_cast<float4*>(Sa + row * LD + 4 * c4) = pa;
+        *reinterpret_cast<float4*>(Sb + row * LD + 4 * c4) = pb;
+    };
+    const int total = 2 * Bp;
+    fetch(0);
+    stage();
+    __syncthreads();
+    for (int v = 0; v < total; v += BKB) {
+        const bool more = v + BKB < total;
+        if (more) fetch(v + BKB);
+#pragma unroll
+        for (int s = 0; s < BKB / 2; ++s) {
+            float af[2], bf[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) af[p] = Sa[(2 * s + kh) * LD + wi * 64 + p * 32 + jj];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) bf[q] = Sb[(2 * s + kh) * LD + wj * 64 + q * 32 + jj];
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[p], bf[q], acc[p][q], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            stage();
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = i0 + wi * 64 + p * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const int j = j0 + wj * 64 + q * 32 + jj;
+                if (i < a.D && j < a.D) a.out[(size_t)i * a.D + j] = acc[p][q][r];
+            }
+}
+
+template <typename ARGS, typename K1, typename K2, typename K4>
+int launch_strip(const ARGS& a, int B, int D, K1 k1, K2 k2, K4 k4, hipStream_t st) {
+    const dim3 grid(D / 32), block(kRhThreads);
+    if (B <= 128) hipLaunchKernelGGL(k1, grid, block, 0, st, a);
+    else if (B <= 256) hipLaunchKernelGGL(k2, grid, block, 0, st, a);
+    else hipLaunchKernelGGL(k4, grid, block, 0, st, a);
+    return check_launch();
+}
+
+bool rh_dims_ok(int B, int D) { return B >= 1 && B <= kRhMaxB && D >= 32 && (D % 32) == 0; }
+
+}  // namespace
+}  // namespace pde
+
+using namespace pde;
+
+extern "C" {
+
+int pde_sym_layer_supported(int32_t B, int32_t D) { return rh_dims_ok(B, D) ? 1 : 0; }
+
+int pde_sym_layer_forward(int32_t B, int32_t D, int32_t act, int32_t training, const float* X, const float* K,
+                          const float* bn_weight, const float* bn_bias, float* running_mean, float* running_var,
+                          float momentum, float eps, const float* base, float scale, float* P, float* H, float* mean,
+                          float* invstd, float* out, void* stream) {
+    if (!rh_dims_ok(B, D)) return PDE_E_BADARG;
+    if (!X || !K || !bn_weight || !bn_bias || !P || !H || !mean || !invstd || !out) return PDE_E_BADARG;
+    if (act < kActIdentity || act > kActTanh) return PDE_E_BADARG;
+    if (!training && (!running_mean || !running_var)) return PDE_E_BADARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    RhFwdArgs f{X, K, bn_weight, bn_bias, running_mean, running_var, P, H, mean, invstd, B, D, act, training ? 1 : 0, momentum, eps};
+    int rc = launch_strip(f, B, D, rh_fwd_strip_kernel<1>, rh_fwd_strip_kernel<2>, rh_fwd_strip_kernel<4>, st);
+    if (rc != PDE_OK) return rc;
+    RhAxpyArgs x{H, K, base, out, B, D, scale};
+    return launch_strip(x, B, D, rh_axpy_strip_kernel<1>, rh_axpy_strip_kernel<2>, rh_axpy_strip_kernel<4>, st);
+}
+
+int pde_sym_layer_backward(int32_t B, int32_t D, int32_t act, int32_t training, const float* g_out, float scale,
+                           const float* X, const float* K, const float* bn_weight, const float* P, const float* H,
+                           const float* mean, const float* invstd, float* dP, float* gX, float* gK,
+                           float* g_bn_weight, float* g_bn_bias, void* stream) {
+    if (!rh_dims_ok(B, D)) return PDE_E_BADARG;
+    if (!g_out || !X || !K || !bn_weight || !P || !H || !mean || !invstd || !dP || !gX || !gK || !g_bn_weight || !g_bn_bias)
+        return PDE_E_BADARG;
+    if (act < kActIdentity || act > kActTanh) return PDE_E_BADARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    RhBwdArgs b{g_out, K, bn_weight, P, H, mean, invstd, dP, g_bn_weight, g_bn_bias, B, D, act, training ? 1 : 0, scale};
+    int rc = launch_strip(b, B, D, rh_bwd_strip_kernel<1>, rh_bwd_strip_kernel<2>, rh_bwd_strip_kernel<4>, st);
+    if (rc != PDE_OK) return rc;
+    RhAxpyArgs x{dP, K, nullptr, gX, B, D, 1.0f};
+    rc = launch_strip(x, B, D, rh_axpy_strip_kernel<1>, rh_axpy_strip_kernel<2>, rh_axpy_strip_kernel<4>, st);
+    if (rc != PDE_OK) return rc;
+    RhOuterArgs o{dP, X, H, g_out, gK, B, D, scale};
+    hipLaunchKernelGGL(rh_outer_kernel, dim3((D + 127) / 128, (D + 127) / 128), dim3(kRhThreads), 0, st, o);
+    return check_launch();
+}
+
+}  // extern "C"

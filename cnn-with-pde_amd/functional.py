@@ -15,7 +15,7 @@ import torch
 from . import _lib as L
 
 __all__ = ["Sweep", "adi_schedule", "adi_diffuse", "adi_diffuse_mixed", "adi_diffuse_small", "adi_small_supported", "adi_diffuse_multi", "gate_combine", "plan_checkpoints", "kappa_max_async", "channel_mix", "skip_blend", "explicit5_step", "jacobi_diffuse",
-           "timing_enable", "timing_read", "Schedule"]
+           "timing_enable", "timing_read", "Schedule", "sym_layer", "sym_layer_supported"]
 
 
 @dataclass(frozen=True)
@@ -814,6 +814,91 @@ def bn_pool(x, bn):
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     return _BnPoolFn.apply(x, bn.weight, bn.bias, rm, rv, training, bn.momentum if bn.momentum is not None else 0.0, bn.eps)
+
+
+# --------------------------------------------------------------------------- Ruthotto-Haber symmetric layer (MFMA)
+_ACT_CODE = {"identity": 0, "relu": 1, "tanh": 2}
+
+
+class _SymLayerFn(torch.autograd.Function):
+    """out = base + scale * (act(BatchNorm1d(X K^T)) K) — cifar_2version.py:190-258 — on the fp32 matrix cores (pde_rh.hip)."""
+
+    @staticmethod
+    def forward(ctx, X, K, gamma, beta, base, running_mean, running_var, training, momentum, eps, scale, act):
+        lib = L.load()
+        _require_cuda(X, K, gamma, beta, base)
+        B, D = X.shape
+        Xf = X.to(torch.float32).contiguous()
+        Kf = K.detach().to(torch.float32).contiguous()
+        gm = gamma.detach().to(torch.float32).contiguous()
+        bt = beta.detach().to(torch.float32).contiguous()
+        bs = None if base is None else base.to(torch.float32).contiguous()
+        dev = X.device
+        P = torch.empty((B, D), dtype=torch.float32, device=dev)
+        H = torch.empty_like(P)
+        out = torch.empty_like(P)
+        mean = torch.empty(D, dtype=torch.float32, device=dev)
+        invstd = torch.empty_like(mean)
+        with torch.cuda.device(dev):
+            L.check(lib.pde_sym_layer_forward(B, D, act, 1 if training else 0, _ptr(Xf), _ptr(Kf), _ptr(gm), _ptr(bt),
+                                              _ptr(running_mean), _ptr(running_var), float(momentum), float(eps), _ptr(bs),
+                                              float(scale), _ptr(P), _ptr(H), _ptr(mean), _ptr(invstd), _ptr(out), _stream()),
+                    "pde_sym_layer_forward")
+        ctx.save_for_backward(Xf, Kf, gm, P, H, mean, invstd)
+        ctx.cfg = (bool(training), float(scale), int(act), base is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = L.load()
+        Xf, Kf, gm, P, H, mean, invstd = ctx.saved_tensors
+        training, scale, act, has_base = ctx.cfg
+        B, D = Xf.shape
+        g = gout.to(torch.float32).contiguous()
+        dev = Xf.device
+        dP = torch.empty_like(Xf)
+        gX = torch.empty_like(Xf)
+        gK = torch.empty_like(Kf)
+        gg = torch.empty(D, dtype=torch.float32, device=dev)
+        gb = torch.empty_like(gg)
+        with torch.cuda.device(dev):
+            L.check(lib.pde_sym_layer_backward(B, D, act, 1 if training else 0, _ptr(g), float(scale), _ptr(Xf), _ptr(Kf),
+                                               _ptr(gm), _ptr(P), _ptr(H), _ptr(mean), _ptr(invstd), _ptr(dP), _ptr(gX),
+                                               _ptr(gK), _ptr(gg), _ptr(gb), _stream()), "pde_sym_layer_backward")
+        return gX, gK, gg, gb, (g if has_base else None), None, None, None, None, None, None, None
+
+
+def sym_layer_supported(X, bn) -> bool:
+    """Whether ``sym_layer`` takes this input: an fp32 CUDA batch of at most 512 rows whose feature count is a multiple of
+    32, outside autocast, and a BatchNorm1d with affine parameters and a fixed momentum."""
+    if not (X.is_cuda and X.dtype == torch.float32 and X.dim() >= 2 and X.shape[0] > 0) or torch.is_autocast_enabled():
+        return False
+    D = X[0].numel()
+    if bn.weight is None or bn.bias is None or (bn.momentum is None and bn.track_running_stats):
+        return False
+    if not bn.training and bn.running_mean is None:
+        pass                                              # eval without running statistics = batch statistics: supported
+    return bool(L.load().pde_sym_layer_supported(X.shape[0], D))
+
+
+def sym_layer(X, K, bn, activation: str = "relu", base=None, scale: float = -1.0):
+    """``base + scale * (act(bn(X @ K.T)) @ K)`` for a dense (D, D) weight ``K`` and a ``torch.nn.BatchNorm1d`` ``bn``
+    (cifar_2version.py:210-219; ``F_sym`` itself is ``base=None, scale=-1``; ParabolicBlock's step is ``base=Y, scale=-dt``,
+    HamiltonianBlock's ``base=Y, scale=+dt`` on Z and ``base=Z, scale=+dt`` on Y).  X: (B, ...) flattened to (B, D); the result
+    has X's shape.  Updates the module's running statistics in training mode exactly as the module would."""
+    shape = X.shape
+    B = shape[0]
+    X2 = X.reshape(B, -1)
+    training = bn.training or bn.running_mean is None
+    track = bn.track_running_stats and bn.running_mean is not None
+    rm = bn.running_mean if (track and bn.training) or not training else None
+    rv = bn.running_var if (track and bn.training) or not training else None
+    if bn.training and track and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    b2 = None if base is None else base.reshape(B, -1)
+    out = _SymLayerFn.apply(X2, K, bn.weight, bn.bias, b2, rm, rv, training, bn.momentum if bn.momentum is not None else 0.0,
+                            bn.eps, scale, _ACT_CODE[activation])
+    return out.view(shape)
 
 
 # --------------------------------------------------------------------------- attention gates + weighted combination

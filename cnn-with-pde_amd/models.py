@@ -12,7 +12,7 @@ as they are in the reference (out of scope as code to accel
     cifar10.MultiScaleExtractor         :248-282           MultiScaleExtractor   (three layers, ONE launch per pass)
     cifar10.EnhancedFC                  :286-314           EnhancedFC
     cifar10.CIFAR10PDENoConv            :318-361           CIFAR10PDENoConv
-    cifar_2version.SymmetricLayer / ParabolicBlock / HamiltonianBlock :190-258   same names (plain torch, rocBLAS)
+    cifar_2version.SymmetricLayer / ParabolicBlock / HamiltonianBlock :190-258   same names (fp32-MFMA kernels, pde_rh.hip)
     cifar_2version.HybridPDEExtractor   :261-302           HybridPDEExtractor    (two diffusion layers in ONE launch per pass)
     cifar_2version.NonConvSpatialAttention / PDEClassifier / CIFAR10HybridPDEModel :305-412
                                                            NonConvSpatialAttention / HybridClassifierHead / CIFAR10HybridPDEModel
@@ -223,8 +223,10 @@ class CIFAR10PDENoConv(nn.Module):
 
 class SymmetricLayer(nn.Module):
     """cifar_2version.py:190-220 (Ruthotto & Haber): F(Y) = -K^T act(BN(K Y)) on the flattened image, K a dense
-    (C*H*W)^2 matrix initialised near the identity.  Plain torch (rocBLAS GEMMs), as in the reference — SURVEY §8f-4:
-    dense contractions, not the stencil path; no custom kernel here."""
+    (C*H*W)^2 matrix initialised near the identity.  On the GPU both products, the BatchNorm1d over the batch and the
+    activation run as two launches on the fp32 matrix cores (``functional.sym_layer``, pde_rh.hip — SURVEY §8f-4);
+    ``residual(base, X, scale)`` is the fused update ``base + scale * (act(BN(X K^T)) K)`` the two blocks below are made
+    of.  ``fused = False`` (or a shape the kernels do not take, or autocast) is plain torch, as in the reference."""
 
     def __init__(self, channels, spatial_size, activation="relu"):
         super().__init__()
@@ -232,11 +234,24 @@ class SymmetricLayer(nn.Module):
         self.feature_dim = channels * spatial_size * spatial_size
         self.K = nn.Linear(self.feature_dim, self.feature_dim, bias=False)
         self.norm = nn.BatchNorm1d(self.feature_dim)
+        self.act_name = activation if activation in ("relu", "tanh") else "identity"
         self.activation = {"relu": nn.ReLU, "tanh": nn.Tanh}.get(activation, nn.Identity)()
+        self.fused = True
         nn.init.eye_(self.K.weight)
         self.K.weight.data += torch.randn_like(self.K.weight) * 0.01
 
+    def _fused_ok(self, X):
+        return self.fused and F_.sym_layer_supported(X, self.norm)
+
+    def residual(self, base, X, scale):
+        """base + scale * (act(BN(X K^T)) K): one step of the Parabolic / Hamiltonian blocks."""
+        if self._fused_ok(X):
+            return F_.sym_layer(X, self.K.weight, self.norm, self.act_name, base=base, scale=scale)
+        return base + scale * (-self.forward(X))
+
     def forward(self, Y):
+        if self._fused_ok(Y):
+            return F_.sym_layer(Y, self.K.weight, self.norm, self.act_name, base=None, scale=-1.0)
         B = Y.shape[0]
         h = self.activation(self.norm(self.K(Y.reshape(B, -1))))
         return (-(h @ self.K.weight)).view_as(Y)
@@ -253,7 +268,7 @@ class ParabolicBlock(nn.Module):
 
     def forward(self, Y):
         for _ in range(self.num_steps):
-            Y = Y + self.dt * self.symmetric_layer(Y)
+            Y = self.symmetric_layer.residual(Y, Y, -self.dt)          # Y + dt * F_sym(Y)
         return Y
 
 
@@ -270,8 +285,8 @@ class HamiltonianBlock(nn.Module):
     def forward(self, Y):
         Z = torch.zeros_like(Y)
         for _ in range(self.num_steps):
-            Y = Y - self.dt * self.F_Y(Z)
-            Z = Z - self.dt * self.F_Z(Y)
+            Y = self.F_Y.residual(Y, Z, self.dt)                       # Y - dt * F_Y(Z)
+            Z = self.F_Z.residual(Z, Y, self.dt)                       # Z - dt * F_Z(Y)
         return Y
 
 

@@ -350,6 +350,31 @@ int pde_jacobi_backward(int32_t B, int32_t H, int32_t W, int32_t nt,
                         float* gu, float* g_a_row, float* g_b_col,
                         void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- Ruthotto-Haber symmetric layer on the fp32 matrix cores ------------- */
+
+/* cifar_2version.py:190-220 SymmetricLayer.forward and the residual steps built on it (ParabolicBlock :223-236,
+ * HamiltonianBlock :239-258), fused:
+ *     P = X K^T;  H = act(BatchNorm1d(P));  out = base + scale * (H K)
+ * X, base, out, P, H: (B, D) fp32 row-major (the image batch flattened, D = C*H*W); K: (D, D) = nn.Linear weight;
+ * bn_weight / bn_bias / running_mean / running_var: (D).  act: 0 identity, 1 relu, 2 tanh (cifar_2version.py:203-208).
+ * training != 0: batch statistics (biased variance for normalisation; running statistics updated with `momentum`
+ * and the unbiased variance, as torch.nn.BatchNorm1d does; running_* may be NULL = not tracked); training == 0:
+ * running statistics.  P, H, mean[D], invstd[D] are written for the backward; base may be NULL (then out = scale*(H K)).
+ * F_sym(Y) itself is base = NULL, scale = -1.  B <= 512, D a multiple of 32 (pde_sym_layer_supported). */
+int pde_sym_layer_supported(int32_t B, int32_t D);
+int pde_sym_layer_forward(int32_t B, int32_t D, int32_t act, int32_t training,
+                          const float* X, const float* K, const float* bn_weight, const float* bn_bias,
+                          float* running_mean, float* running_var, float momentum, float eps,
+                          const float* base, float scale,
+                          float* P, float* H, float* mean, float* invstd, float* out, void* stream);
+/* Backward of the above for an upstream gradient g_out (B, D) of `out` (the gradient of `base` is g_out itself and is
+ * left to the caller).  dP: (B, D) scratch.  Overwritten: gX (B, D), gK (D, D) — both uses of K —, g_bn_weight[D],
+ * g_bn_bias[D]. */
+int pde_sym_layer_backward(int32_t B, int32_t D, int32_t act, int32_t training,
+                           const float* g_out, float scale, const float* X, const float* K, const float* bn_weight,
+                           const float* P, const float* H, const float* mean, const float* invstd,
+                           float* dP, float* gX, float* gK, float* g_bn_weight, float* g_bn_bias, void* stream);
+
 /* ---- utilities ------------------------------------------------------------------------- */
 
 /* Average device time (ms) per launch of the dominant kernel of the most recent

@@ -16,6 +16,8 @@ autograd, of the arithmetic of the reference's seven layer classes:
     K2 (explicit 5-point)
         tiny_imagenet.ImprovedDiffusionLayer tiny_imagenet.py:14-72
         emotion_recognition.PDELayer         emotion_recognition.py:56-97
+    Ruthotto-Haber blocks (dense symmetric layer)
+        cifar_2version.SymmetricLayer / ParabolicBlock / HamiltonianBlock   cifar_2version.py:190-258
 
 Pinning: the reference has no tests or golden vectors of its own,
 so the pins are the vectors in ``tests/golden/*.npz`` produced by running the
@@ -326,6 +328,71 @@ def emotion_init_params(dtype=torch.float32) -> Dict[str, torch.Tensor]:
 # --------------------------------------------------------------------------- #
 # helpers shared by tests and bench                                            #
 # --------------------------------------------------------------------------- #
+# ---- Ruthotto-Haber blocks (cifar_2version.py:190-258) ---------------------------------------------------------
+def batch_norm_1d(P: torch.Tensor, weight, bias, running_mean, running_var, training: bool, momentum=0.1, eps=1e-5):
+    """nn.BatchNorm1d on a (B, D) input, spelled out (cifar_2version.py:201, 215): batch statistics with the biased
+    variance in training mode — the running statistics move by ``momentum`` towards the batch mean and the UNBIASED
+    variance —, running statistics otherwise.  Returns (output, new_running_mean, new_running_var)."""
+    if training:
+        B = P.shape[0]
+        mean = P.mean(dim=0)
+        var = ((P - mean) ** 2).mean(dim=0)
+        new_rm, new_rv = running_mean, running_var
+        if running_mean is not None:
+            unb = var * (B / (B - 1)) if B > 1 else var
+            new_rm = (1 - momentum) * running_mean + momentum * mean.detach()
+            new_rv = (1 - momentum) * running_var + momentum * unb.detach()
+    else:
+        mean, var = running_mean, running_var
+        new_rm, new_rv = running_mean, running_var
+    out = (P - mean) / torch.sqrt(var + eps) * weight + bias
+    return out, new_rm, new_rv
+
+
+def _rh_act(x, activation: str):
+    return torch.relu(x) if activation == "relu" else (torch.tanh(x) if activation == "tanh" else x)      # :203-208
+
+
+def symmetric_layer(Y: torch.Tensor, sl: Dict[str, torch.Tensor], training: bool, activation: str = "relu"):
+    """cifar_2version.py:210-219: F_sym(Y) = -act(BN(Y_flat K^T)) K.  ``sl``: K.weight, norm.weight, norm.bias,
+    norm.running_mean, norm.running_var (the last two are replaced by their updated values in training mode)."""
+    B = Y.shape[0]
+    KY = Y.reshape(B, -1) @ sl["K.weight"].t()                                           # :213
+    KYn, rm, rv = batch_norm_1d(KY, sl["norm.weight"], sl["norm.bias"], sl.get("norm.running_mean"),
+                                sl.get("norm.running_var"), training)                   # :214
+    if rm is not None:
+        sl["norm.running_mean"], sl["norm.running_var"] = rm, rv
+    return (-(_rh_act(KYn, activation) @ sl["K.weight"])).view_as(Y)                    # :215-219
+
+
+def _sub(params: Dict[str, torch.Tensor], prefix: str) -> Dict[str, torch.Tensor]:
+    return {k[len(prefix):]: v for k, v in params.items() if k.startswith(prefix)}
+
+
+def parabolic_block(Y, params: Dict[str, torch.Tensor], num_steps: int, dt: float, training: bool):
+    """cifar_2version.py:231-236: Y <- Y + dt * F_sym(Y), num_steps times (one SymmetricLayer, reused)."""
+    sl = _sub(params, "symmetric_layer.")
+    for _ in range(num_steps):
+        Y = Y + dt * symmetric_layer(Y, sl, training)
+    for k, v in sl.items():
+        params["symmetric_layer." + k] = v
+    return Y
+
+
+def hamiltonian_block(Y, params: Dict[str, torch.Tensor], num_steps: int, dt: float, training: bool):
+    """cifar_2version.py:249-258: Z = 0; Y <- Y + dt * (-F_Y(Z)); Z <- Z - dt * F_Z(Y)."""
+    fy, fz = _sub(params, "F_Y."), _sub(params, "F_Z.")
+    Z = torch.zeros_like(Y)
+    for _ in range(num_steps):
+        Y = Y + dt * (-symmetric_layer(Z, fy, training))
+        Z = Z - dt * symmetric_layer(Y, fz, training)
+    for k, v in fy.items():
+        params["F_Y." + k] = v
+    for k, v in fz.items():
+        params["F_Z." + k] = v
+    return Y
+
+
 def value_and_grads(fn, u: torch.Tensor, params: Dict[str, torch.Tensor], gy: torch.Tensor):
     """Run ``fn(u, params)`` with autograd; return (y, grad_u, {name: grad})."""
     u = u.detach().clone().requires_grad_(True)

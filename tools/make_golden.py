@@ -37,8 +37,12 @@ def _run(layer, u, gy):
 
 
 def _save(name, script, cls, ctor, layer, u, gy, dtype):
+    bufin = {"bufin_" + n: b.detach().clone() for n, b in layer.named_buffers()} if getattr(layer, "keep_buffers", False) else {}
     res = _run(layer, u, gy)
     blob = {"u": u, "gy": gy}
+    blob.update(bufin)
+    if bufin:                                            # what one training-mode forward left in the buffers
+        blob.update({"bufout_" + n: b.detach().clone() for n, b in layer.named_buffers()})
     for n, p in layer.named_parameters():
         blob["param_" + n] = p.detach()
     blob.update(res)
@@ -90,7 +94,7 @@ def _make(name, script, cls, ctor, B, g, dtype, tweak, u_fn, mod):
     _save(name, script, cls, ctor, layer, u, gy, dtype)
 
 
-def make_model(name, script, cls, ctor, shape, seed, tweak=None, out_index=0, eval_mode=True):
+def make_model(name, script, cls, ctor, shape, seed, tweak=None, out_index=0, eval_mode=True, buffers=False):
     """A fixture of one of the reference's MODELS around the layers (tests/golden_models): same format, the output is
     element ``out_index`` of what the module returns.  eval(): dropout off, batch norm on its running statistics."""
     mod = ref_loader.load(script)
@@ -120,6 +124,10 @@ def make_model(name, script, cls, ctor, shape, seed, tweak=None, out_index=0, ev
 
         def named_parameters(self, *a, **k):
             return model.named_parameters(*a, **k)
+
+        def named_buffers(self, *a, **k):
+            return model.named_buffers(*a, **k)
+    W.keep_buffers = buffers
     global OUT
     keep, OUT = OUT, os.path.join(os.path.dirname(HERE), "tests", "golden_models")
     os.makedirs(OUT, exist_ok=True)
@@ -155,6 +163,66 @@ def models():
             m.combination_weights.copy_(torch.tensor([0.3, -0.2, 0.1, 0.4]))
     make_model("model_cifar2_hybrid_8", "cifar_2version", "HybridPDEExtractor", {"input_size": 8, "channels": 3},
                (4, 3, 8, 8), 83, tweak=live2)
+
+    # the Ruthotto-Haber blocks alone (cifar_2version.py:190-258) at 8x8 (K is 192^2), training mode (batch statistics,
+    # running statistics updated) and eval mode (running statistics), BatchNorm affine parameters and running
+    # statistics away from their initial values
+    def rh(m, g):
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                if n.endswith("norm.weight"):
+                    p.copy_(1 + 0.3 * torch.randn(p.shape, generator=g))
+                elif n.endswith("norm.bias"):
+                    p.copy_(0.2 * torch.randn(p.shape, generator=g))
+                elif n.endswith("K.weight"):
+                    p.copy_(torch.eye(p.shape[0]) + 0.05 * torch.randn(p.shape, generator=g))
+            for n, b in m.named_buffers():
+                if n.endswith("running_mean"):
+                    b.copy_(0.3 * torch.randn(b.shape, generator=g))
+                elif n.endswith("running_var"):
+                    b.copy_(0.5 + torch.rand(b.shape, generator=g))
+    for mode, ev in (("train", False), ("eval", True)):
+        make_model(f"model_rh_symmetric_8_{mode}", "cifar_2version", "SymmetricLayer", {"channels": 3, "spatial_size": 8},
+                   (12, 3, 8, 8), 91, tweak=rh, eval_mode=ev, buffers=True)
+        make_model(f"model_rh_symmetric_tanh_8_{mode}", "cifar_2version", "SymmetricLayer",
+                   {"channels": 3, "spatial_size": 8, "activation": "tanh"}, (7, 3, 8, 8), 92, tweak=rh, eval_mode=ev, buffers=True)
+        make_model(f"model_rh_parabolic_8_{mode}", "cifar_2version", "ParabolicBlock",
+                   {"channels": 3, "spatial_size": 8, "num_steps": 4, "dt": 0.5}, (12, 3, 8, 8), 93, tweak=rh, eval_mode=ev, buffers=True)
+        make_model(f"model_rh_hamiltonian_8_{mode}", "cifar_2version", "HamiltonianBlock",
+                   {"channels": 3, "spatial_size": 8, "num_steps": 3, "dt": 0.8}, (12, 3, 8, 8), 94, tweak=rh, eval_mode=ev, buffers=True)
+    # one application at the reference's own size (3 x 32 x 32: K is 3072^2, 37.7 MB — too large to store): K is rebuilt from
+    # its seed by the test (eye + 0.01 randn, torch's CPU generator), its gradient is held by two projections
+    big_symmetric()
+
+
+def big_symmetric():
+    mod = ref_loader.load("cifar_2version")
+    g = torch.Generator().manual_seed(95)
+    with ref_loader.quiet():
+        layer = mod.SymmetricLayer(3, 32)
+    D = layer.feature_dim
+    with torch.no_grad():
+        layer.K.weight.copy_(torch.eye(D) + 0.01 * torch.randn(D, D, generator=g))
+        layer.norm.weight.copy_(1 + 0.3 * torch.randn(D, generator=g))
+        layer.norm.bias.copy_(0.2 * torch.randn(D, generator=g))
+    u = torch.randn(16, 3, 32, 32, generator=g).requires_grad_(True)
+    gy = torch.randn(16, 3, 32, 32, generator=g)
+    v1 = torch.randn(D, generator=g)
+    v2 = torch.randn(D, generator=g)
+    layer.train()
+    y = layer(u)
+    gu, gK, gw, gb = torch.autograd.grad(y, [u, layer.K.weight, layer.norm.weight, layer.norm.bias], gy)
+    arrays = {"u": u.detach(), "gy": gy, "y": y.detach(), "gu": gu, "grad_norm.weight": gw, "grad_norm.bias": gb,
+              "param_norm.weight": layer.norm.weight.detach(), "param_norm.bias": layer.norm.bias.detach(),
+              "v1": v1, "v2": v2, "gK_v1": gK @ v1, "v2_gK": v2 @ gK, "gK_absmax": gK.abs().max(),
+              "bufout_norm.running_mean": layer.norm.running_mean.clone(), "bufout_norm.running_var": layer.norm.running_var.clone()}
+    arrays = {k: v.detach().cpu().numpy() for k, v in arrays.items()}
+    meta = {"script": "cifar_2version", "cls": "SymmetricLayer", "ctor": {"channels": 3, "spatial_size": 32}, "dtype": "float32",
+            "K": "eye(3072) + 0.01 * randn(3072, 3072, generator=manual_seed(95)) — the FIRST draw of the generator"}
+    arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(os.path.dirname(HERE), "tests", "golden_models", "model_rh_symmetric_32_train.npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{'model_rh_symmetric_32_train':40s} {os.path.getsize(path) / 1024:8.1f} KiB")
 
 
 def main():
