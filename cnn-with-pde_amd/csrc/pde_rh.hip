@@ -3,10 +3,10 @@
 //     F_sym(Y) = -act(BN(Y K^T)) K            Y: (B, D) flattened image batch, K: (D, D) dense, D = C*H*W (3072)
 //
 // and the residual steps built on it (ParabolicBlock :223-236, HamiltonianBlock :239-258), which all have the form
-// out = base + scale * (act(BN(X K^T)) K).  Three kernels, all v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains, the fp32
-// vector rate, VALU left free for the epilogues):
+// out = base + scale * (act(BN(X K^T)) K).  Three kernels on the fp32-input MFMAs (v_mfma_f32_16x16x4_f32 / 32x32x2_f32:
+// exact fp32 FMA chains at the fp32 vector rate, VALU left free for the epilogues):
 //
-//   strip kernel, NT  P = X K^T for ALL batch rows and a strip of 32 output features per workgroup, so the BatchNorm1d
+//   strip kernel, NT  P = X K^T for ALL batch rows and a strip of 16 output features per workgroup, so the BatchNorm1d
 //                     statistics of a feature (over the batch) are workgroup-local and normalisation + activation are
 //                     the epilogue of the product (forward); in the backward the same product shape carries
 //                     dH = dF K^T with the activation derivative and the BatchNorm backward (two per-feature sums)
@@ -22,113 +22,124 @@ namespace pde {
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kRhThreads = 256;          // 4 waves, one per SIMD
-constexpr int kRhBK = 16;                // contraction slab
-constexpr int kRhLdA = 18;               // LDS row stride of a [rows][16] slab: ds_read_b64 by 32 rows hits 32 distinct bank pairs
-constexpr int kRhLdN = 32;               // LDS row stride of a [16][32] slab (NN operand)
-constexpr int kRhMaxB = 512;             // batch rows a strip workgroup can hold (4 row blocks of 32 per wave)
+constexpr int kRhThreads = 256;          // outer kernel: 4 waves
+constexpr int kRhStripThreads = 512;     // strip kernels: 8 waves, two per SIMD
+constexpr int kRhWaves = 8;
+constexpr int kRhCols = 16;              // output features per strip workgroup: D/16 workgroups (192 for D = 3072)
+// contraction slab of a strip workgroup with R row blocks per wave: 64 / R, so that the X slab (128 R rows) stays ~35 KB
+// and two of them (double buffering: one barrier per slab) fit beside each other whatever the batch
+template <int R> struct RhSlab { static constexpr int BK = 64 / R, LDA = BK + 4; };
+constexpr int kRhLdN = 20;               // LDS row stride of a [BK][16] slab (NN operand): the four k-quarters hit disjoint banks
+constexpr int kRhMaxB = 512;             // batch rows a strip workgroup can hold (4 row blocks of 16 per wave)
 
 enum { kActIdentity = 0, kActRelu = 1, kActTanh = 2 };
 
-// ---- strip product: acc[b][j] = sum_k X[b][k] * Wop[k][j] for every batch row (padded to a multiple of 32) ----
+// ---- strip product: acc[b][j] = sum_k X[b][k] * Wop[k][j] for every batch row (padded) and 16 output features ----
 //   NT: Wop[k][j] = W[(n0 + j) * ldw + k]        NN: Wop[k][j] = W[k * ldw + n0 + j]
-// Wave w owns the row blocks w, w + 4, ... (RBW of them).  Contraction order inside a slab of 16: MFMA step 2t takes
-// k = 4t + 2*kh, step 2t + 1 takes k = 4t + 2*kh + 1 (kh = lane >> 5) — one 8-byte LDS read feeds two steps.
-template <int RBW, bool NT>
+// v_mfma_f32_16x16x4_f32: A lane l holds A[i = l & 15][k = l >> 4], B lane l holds B[k = l >> 4][j = l & 15], D lane l
+// holds rows 4 * (l >> 4) + r (r = 0..3) of column l & 15.  Wave w owns the row blocks (16 rows) w, w + 8, ... (R of
+// them).  Contraction order inside a group of 16: step s (0..3) takes k = 4 * kq + s from quarter kq = l >> 4 — one
+// 16-byte LDS read feeds four steps.  16 columns per workgroup instead of 32 (v_mfma_f32_32x32x2_f32) because a
+// batch of 128 is only 96 strips of 32: with 192 the product runs on three quarters of the chip instead of three eighths.
+template <int R, bool NT>
 __device__ __forceinline__ void strip_gemm(const float* __restrict__ X, int B, int Kdim, int ldx, const float* __restrict__ W,
-                                           int ldw, int n0, f32x16 (&acc)[RBW], float* As, float* Ws) {
+                                           int ldw, int n0, f32x4 (&acc)[R], float* As, float* Ws) {
+    constexpr int BK = RhSlab<R>::BK, LDA = RhSlab<R>::LDA;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int jj = lane & 31, kh = lane >> 5;
-    constexpr int RB = 4 * RBW;                           // row blocks held by the workgroup
-    constexpr int AF4 = RB * 32 * kRhBK / 4;              // float4 of an X slab
-    constexpr int APT = AF4 / kRhThreads;                 // per thread (RBW * 2)
+    const int jj = lane & 15, kq = lane >> 4;
+    constexpr int ROWS = kRhWaves * R * 16;               // padded batch rows held by the workgroup
+    constexpr int C4 = BK / 4;                            // float4 per slab row
+    constexpr int APT = ROWS * C4 / kRhStripThreads;      // X-slab float4 per thread (4)
+    constexpr int WF4 = kRhCols * BK / 4;                 // W-slab float4 (<= 256)
+    constexpr int ASZ = ROWS * LDA, WSZ = NT ? kRhCols * LDA : BK * kRhLdN;      // floats per buffer
 #pragma unroll
-    for (int m = 0; m < RBW; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    for (int m = 0; m < R; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     float4 pa[APT], pw;
     auto fetch = [&](int k0) __attribute__((always_inline)) {
 #pragma unroll
         for (int m = 0; m < APT; ++m) {
-            const int f = tid + kRhThreads * m, row = f >> 2, c4 = f & 3;
+            const int f = tid + kRhStripThreads * m, row = f / C4, c4 = f % C4;
             pa[m] = (row < B) ? *reinterpret_cast<const float4*>(X + (size_t)row * ldx + k0 + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        if (tid < 128) {
+        if (tid < WF4) {
             if (NT) {
-                const int row = tid >> 2, c4 = tid & 3;   // feature n0 + row, k0 + 4 c4
+                const int row = tid / C4, c4 = tid % C4;  // feature n0 + row, k0 + 4 c4
                 pw = *reinterpret_cast<const float4*>(W + (size_t)(n0 + row) * ldw + k0 + 4 * c4);
             } else {
-                const int row = tid >> 3, c4 = tid & 7;   // k0 + row, features n0 + 4 c4
+                const int row = tid >> 2, c4 = tid & 3;   // k0 + row, features n0 + 4 c4
                 pw = *reinterpret_cast<const float4*>(W + (size_t)(k0 + row) * ldw + n0 + 4 * c4);
             }
         }
     };
-    auto stage = [&]() __attribute__((always_inline)) {
+    auto stage = [&](int buf) __attribute__((always_inline)) {
+        float* A = As + buf * ASZ;
+        float* Wb = Ws + buf * WSZ;
 #pragma unroll
         for (int m = 0; m < APT; ++m) {
-            const int f = tid + kRhThreads * m, row = f >> 2, c4 = f & 3;
-            float* d = As + row * kRhLdA + 4 * c4;
-            *reinterpret_cast<float2*>(d) = make_float2(pa[m].x, pa[m].y);
-            *reinterpret_cast<float2*>(d + 2) = make_float2(pa[m].z, pa[m].w);
+            const int f = tid + kRhStripThreads * m, row = f / C4, c4 = f % C4;
+            *reinterpret_cast<float4*>(A + row * LDA + 4 * c4) = pa[m];
         }
-        if (tid < 128) {
+        if (tid < WF4) {
             if (NT) {
-                const int row = tid >> 2, c4 = tid & 3;
-                float* d = Ws + row * kRhLdA + 4 * c4;
-                *reinterpret_cast<float2*>(d) = make_float2(pw.x, pw.y);
-                *reinterpret_cast<float2*>(d + 2) = make_float2(pw.z, pw.w);
+                const int row = tid / C4, c4 = tid % C4;
+                *reinterpret_cast<float4*>(Wb + row * LDA + 4 * c4) = pw;
             } else {
-                const int row = tid >> 3, c4 = tid & 7;
-                *reinterpret_cast<float4*>(Ws + row * kRhLdN + 4 * c4) = pw;
+                const int row = tid >> 2, c4 = tid & 3;
+                *reinterpret_cast<float4*>(Wb + row * kRhLdN + 4 * c4) = pw;
             }
         }
     };
     fetch(0);
-    stage();
+    stage(0);
     __syncthreads();
-    for (int k0 = 0; k0 < Kdim; k0 += kRhBK) {
-        const bool more = k0 + kRhBK < Kdim;
-        if (more) fetch(k0 + kRhBK);
+    int buf = 0;
+    for (int k0 = 0; k0 < Kdim; k0 += BK) {
+        const bool more = k0 + BK < Kdim;
+        if (more) fetch(k0 + BK);                         // global -> registers while the matrix cores work on this slab
+        const float* A = As + buf * ASZ;
+        const float* Wb = Ws + buf * WSZ;
 #pragma unroll
-        for (int t = 0; t < kRhBK / 4; ++t) {
-            float b0, b1;
+        for (int t = 0; t < BK / 16; ++t) {
+            float b[4];
             if (NT) {
-                const float2 bv = *reinterpret_cast<const float2*>(Ws + jj * kRhLdA + 4 * t + 2 * kh);
-                b0 = bv.x; b1 = bv.y;
+                const float4 bv = *reinterpret_cast<const float4*>(Wb + jj * LDA + 16 * t + 4 * kq);
+                b[0] = bv.x; b[1] = bv.y; b[2] = bv.z; b[3] = bv.w;
             } else {
-                b0 = Ws[(4 * t + 2 * kh) * kRhLdN + jj];
-                b1 = Ws[(4 * t + 2 * kh + 1) * kRhLdN + jj];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) b[s] = Wb[(16 * t + 4 * kq + s) * kRhLdN + jj];
             }
 #pragma unroll
-            for (int m = 0; m < RBW; ++m) {
-                const int rb = wave + 4 * m;
-                const float2 av = *reinterpret_cast<const float2*>(As + (rb * 32 + jj) * kRhLdA + 4 * t + 2 * kh);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1, acc[m], 0, 0, 0);
+            for (int m = 0; m < R; ++m) {
+                const int rb = wave + kRhWaves * m;
+                const float4 av = *reinterpret_cast<const float4*>(A + (rb * 16 + jj) * LDA + 16 * t + 4 * kq);
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b[0], acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b[1], acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b[2], acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b[3], acc[m], 0, 0, 0);
             }
         }
+        if (more) stage(buf ^ 1);                         // the other buffer: last read one barrier ago
         __syncthreads();
-        if (more) {
-            stage();
-            __syncthreads();
-        }
+        buf ^= 1;
     }
 }
 
-// row of accumulator register r of row block rb for this lane (column = n0 + (lane & 31))
-__device__ __forceinline__ int acc_row(int rb, int r, int kh) { return rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh; }
+// batch row of accumulator component r of this wave's m-th row block (column = n0 + (lane & 15))
+__device__ __forceinline__ int acc_row(int wave, int m, int r, int kq) { return (wave + kRhWaves * m) * 16 + 4 * kq + r; }
 
-// sum over the whole workgroup of a per-lane value that belongs to column (lane & 31): every lane gets its column's total
+// sum over the whole workgroup of a per-lane value that belongs to column (lane & 15): every lane gets its column's total
 __device__ __forceinline__ float column_total(float v, float* red) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, jj = lane & 31;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, jj = lane & 15;
     __syncthreads();                                      // `red` may still be read from the previous call
     red[wave * 64 + lane] = v;
     __syncthreads();
     float s = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) s += red[w * 64 + jj] + red[w * 64 + 32 + jj];     // fixed order: deterministic
+    for (int w = 0; w < kRhWaves; ++w)                    // fixed order: deterministic
+        s += (red[w * 64 + jj] + red[w * 64 + 16 + jj]) + (red[w * 64 + 32 + jj] + red[w * 64 + 48 + jj]);
     return s;
 }
 
@@ -149,35 +160,36 @@ struct RhFwdArgs {
 };
 
 // P = X K^T, BatchNorm1d over the batch (cifar_2version.py:201, 214-215), activation (:216)
-template <int RBW>
-__global__ __launch_bounds__(kRhThreads) void rh_fwd_strip_kernel(RhFwdArgs a) {
-    __shared__ __attribute__((aligned(16))) float As[4 * RBW * 32 * kRhLdA];
-    __shared__ __attribute__((aligned(16))) float Ws[32 * kRhLdA];
-    __shared__ float red[4 * 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, jj = lane & 31, kh = lane >> 5;
-    const int n0 = blockIdx.x * 32, col = n0 + jj;
-    f32x16 acc[RBW];
-    strip_gemm<RBW, true>(a.X, a.B, a.D, a.D, a.K, a.D, n0, acc, As, Ws);
+template <int R>
+__global__ __launch_bounds__(kRhStripThreads) void rh_fwd_strip_kernel(RhFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float rh_smem[];
+    float* As = rh_smem;                                                 // [2][128 R][LDA]
+    float* Ws = As + 2 * kRhWaves * R * 16 * RhSlab<R>::LDA;             // [2][16][LDA]
+    float* red = Ws + 2 * kRhCols * RhSlab<R>::LDA;                      // [8][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, jj = lane & 15, kq = lane >> 4;
+    const int n0 = blockIdx.x * kRhCols, col = n0 + jj;
+    f32x4 acc[R];
+    strip_gemm<R, true>(a.X, a.B, a.D, a.D, a.K, a.D, n0, acc, As, Ws);
 
     float mu, istd;
     if (a.training) {
         float s = 0.f;
 #pragma unroll
-        for (int m = 0; m < RBW; ++m)
+        for (int m = 0; m < R; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s += acc[m][r];  // padded rows hold exact zeros
+            for (int r = 0; r < 4; ++r) s += acc[m][r];   // padded rows hold exact zeros
         mu = column_total(s, red) / (float)a.B;
         float q = 0.f;
 #pragma unroll
-        for (int m = 0; m < RBW; ++m)
+        for (int m = 0; m < R; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int r = 0; r < 4; ++r) {
                 const float dlt = acc[m][r] - mu;
-                if (acc_row(wave + 4 * m, r, kh) < a.B) q = fmaf(dlt, dlt, q);
+                if (acc_row(wave, m, r, kq) < a.B) q = fmaf(dlt, dlt, q);
             }
         const float var = column_total(q, red) / (float)a.B;             // biased, as BatchNorm normalises
         istd = 1.0f / sqrtf(var + a.eps);
-        if (threadIdx.x < 32 && a.run_mean != nullptr) {                  // running statistics (unbiased variance)
+        if (threadIdx.x < kRhCols && a.run_mean != nullptr) {             // running statistics (unbiased variance)
             const float unb = a.B > 1 ? var * (float)a.B / (float)(a.B - 1) : var;
             a.run_mean[col] = (1.f - a.momentum) * a.run_mean[col] + a.momentum * mu;
             a.run_var[col] = (1.f - a.momentum) * a.run_var[col] + a.momentum * unb;
@@ -186,13 +198,13 @@ __global__ __launch_bounds__(kRhThreads) void rh_fwd_strip_kernel(RhFwdArgs a) {
         mu = a.run_mean[col];
         istd = 1.0f / sqrtf(a.run_var[col] + a.eps);
     }
-    if (threadIdx.x < 32) { a.mean[col] = mu; a.invstd[col] = istd; }
+    if (threadIdx.x < kRhCols) { a.mean[col] = mu; a.invstd[col] = istd; }
     const float g = a.gamma[col], bt = a.beta[col];
 #pragma unroll
-    for (int m = 0; m < RBW; ++m)
+    for (int m = 0; m < R; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = acc_row(wave + 4 * m, r, kh);
+        for (int r = 0; r < 4; ++r) {
+            const int row = acc_row(wave, m, r, kq);
             if (row < a.B) {
                 const float p = acc[m][r];
                 const float hn = fmaf((p - mu) * istd, g, bt);
@@ -209,19 +221,20 @@ struct RhAxpyArgs {
 };
 
 // out = base + scale * (X K)     (cifar_2version.py:217 and the residual updates :234, :254-255; backward: dX = dP K)
-template <int RBW>
-__global__ __launch_bounds__(kRhThreads) void rh_axpy_strip_kernel(RhAxpyArgs a) {
-    __shared__ __attribute__((aligned(16))) float As[4 * RBW * 32 * kRhLdA];
-    __shared__ __attribute__((aligned(16))) float Ws[kRhBK * kRhLdN];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, jj = lane & 31, kh = lane >> 5;
-    const int n0 = blockIdx.x * 32, col = n0 + jj;
-    f32x16 acc[RBW];
-    strip_gemm<RBW, false>(a.X, a.B, a.D, a.D, a.K, a.D, n0, acc, As, Ws);
+template <int R>
+__global__ __launch_bounds__(kRhStripThreads) void rh_axpy_strip_kernel(RhAxpyArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float rh_smem[];
+    float* As = rh_smem;
+    float* Ws = As + 2 * kRhWaves * R * 16 * RhSlab<R>::LDA;             // [2][BK][20]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, jj = lane & 15, kq = lane >> 4;
+    const int n0 = blockIdx.x * kRhCols, col = n0 + jj;
+    f32x4 acc[R];
+    strip_gemm<R, false>(a.X, a.B, a.D, a.D, a.K, a.D, n0, acc, As, Ws);
 #pragma unroll
-    for (int m = 0; m < RBW; ++m)
+    for (int m = 0; m < R; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = acc_row(wave + 4 * m, r, kh);
+        for (int r = 0; r < 4; ++r) {
+            const int row = acc_row(wave, m, r, kq);
             if (row < a.B) {
                 const size_t o = (size_t)row * a.D + col;
                 a.out[o] = a.base != nullptr ? fmaf(a.scale, acc[m][r], a.base[o]) : a.scale * acc[m][r];
@@ -238,23 +251,24 @@ struct RhBwdArgs {
 };
 
 // dH = scale * (G K^T); through the activation and the BatchNorm (training: batch statistics take part) -> dP, dgamma, dbeta
-template <int RBW>
-__global__ __launch_bounds__(kRhThreads) void rh_bwd_strip_kernel(RhBwdArgs a) {
-    __shared__ __attribute__((aligned(16))) float As[4 * RBW * 32 * kRhLdA];
-    __shared__ __attribute__((aligned(16))) float Ws[32 * kRhLdA];
-    __shared__ float red[4 * 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, jj = lane & 31, kh = lane >> 5;
-    const int n0 = blockIdx.x * 32, col = n0 + jj;
-    f32x16 acc[RBW];
-    strip_gemm<RBW, true>(a.G, a.B, a.D, a.D, a.K, a.D, n0, acc, As, Ws);
+template <int R>
+__global__ __launch_bounds__(kRhStripThreads) void rh_bwd_strip_kernel(RhBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float rh_smem[];
+    float* As = rh_smem;
+    float* Ws = As + 2 * kRhWaves * R * 16 * RhSlab<R>::LDA;
+    float* red = Ws + 2 * kRhCols * RhSlab<R>::LDA;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, jj = lane & 15, kq = lane >> 4;
+    const int n0 = blockIdx.x * kRhCols, col = n0 + jj;
+    f32x4 acc[R];
+    strip_gemm<R, true>(a.G, a.B, a.D, a.D, a.K, a.D, n0, acc, As, Ws);
     const float mu = a.mean[col], istd = a.invstd[col], g = a.gamma[col];
     float sb = 0.f, sg = 0.f;
-    f32x16 xh[RBW];
+    f32x4 xh[R];
 #pragma unroll
-    for (int m = 0; m < RBW; ++m)
+    for (int m = 0; m < R; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = acc_row(wave + 4 * m, r, kh);
+        for (int r = 0; r < 4; ++r) {
+            const int row = acc_row(wave, m, r, kq);
             float dhn = 0.f, xhat = 0.f;
             if (row < a.B) {
                 const size_t o = (size_t)row * a.D + col;
@@ -268,13 +282,13 @@ __global__ __launch_bounds__(kRhThreads) void rh_bwd_strip_kernel(RhBwdArgs a) {
         }
     const float dbeta = column_total(sb, red);
     const float dgamma = column_total(sg, red);
-    if (threadIdx.x < 32) { a.g_beta[col] = dbeta; a.g_gamma[col] = dgamma; }
+    if (threadIdx.x < kRhCols) { a.g_beta[col] = dbeta; a.g_gamma[col] = dgamma; }
     const float inv_b = 1.0f / (float)a.B;
 #pragma unroll
-    for (int m = 0; m < RBW; ++m)
+    for (int m = 0; m < R; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = acc_row(wave + 4 * m, r, kh);
+        for (int r = 0; r < 4; ++r) {
+            const int row = acc_row(wave, m, r, kq);
             if (row < a.B) {
                 const float dhn = acc[m][r];
                 const float dp = a.training ? g * istd * (dhn - (dbeta + xh[m][r] * dgamma) * inv_b) : g * istd * dhn;
@@ -362,16 +376,26 @@ __global__ __launch_bounds__(kRhThreads) void rh_outer_kernel(RhOuterArgs a) {
             }
 }
 
-template <typename ARGS, typename K1, typename K2, typename K4>
-int launch_strip(const ARGS& a, int B, int D, K1 k1, K2 k2, K4 k4, hipStream_t st) {
-    const dim3 grid(D / 32), block(kRhThreads);
-    if (B <= 128) hipLaunchKernelGGL(k1, grid, block, 0, st, a);
-    else if (B <= 256) hipLaunchKernelGGL(k2, grid, block, 0, st, a);
-    else hipLaunchKernelGGL(k4, grid, block, 0, st, a);
+template <int R> constexpr size_t strip_lds() {
+    // X slabs + the larger of the two W-slab shapes, both double-buffered, + the reduction scratch
+    return (size_t)(2 * kRhWaves * R * 16 * RhSlab<R>::LDA + 2 * (kRhCols * RhSlab<R>::LDA > RhSlab<R>::BK * kRhLdN
+                    ? kRhCols * RhSlab<R>::LDA : RhSlab<R>::BK * kRhLdN) + kRhWaves * 64) * sizeof(float);
+}
+template <int R, typename ARGS, typename KERN>
+int launch_one(KERN kern, const ARGS& a, int D, hipStream_t st) {
+    static unsigned long long configured = 0;             // one per kernel instantiation
+    if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)strip_lds<R>(), configured) != PDE_OK) return PDE_E_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(D / kRhCols), dim3(kRhStripThreads), strip_lds<R>(), st, a);
     return check_launch();
 }
+template <typename ARGS, typename K1, typename K2, typename K4>
+int launch_strip(const ARGS& a, int B, int D, K1 k1, K2 k2, K4 k4, hipStream_t st) {
+    if (B <= 128) return launch_one<1>(k1, a, D, st);
+    if (B <= 256) return launch_one<2>(k2, a, D, st);
+    return launch_one<4>(k4, a, D, st);
+}
 
-bool rh_dims_ok(int B, int D) { return B >= 1 && B <= kRhMaxB && D >= 32 && (D % 32) == 0; }
+bool rh_dims_ok(int B, int D) { return B >= 1 && B <= kRhMaxB && D >= 64 && (D % 64) == 0; }
 
 }  // namespace
 }  // namespace pde
