@@ -7,6 +7,8 @@ memory, streams and autograd bookkeeping.  Nothing here has a CPU or eager fallb
 from __future__ import annotations
 
 import ctypes as C
+import threading
+import weakref
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -194,32 +196,48 @@ _kmax_rings = {}
 
 
 class _KmaxEntry:
-    __slots__ = ("host", "event", "gen")
+    __slots__ = ("host", "event", "gen", "owner")
+
+
+_kmax_lock = threading.Lock()
 
 
 def _kmax_channel(n: int):
     """Pinned host buffer and an event for the early copy of the per-sweep coefficient maxima (pde_adi_forward copies
     and records, right behind the factorisation kernel).  Creating a pinned tensor and an event per call costs more
-    host time than the launches of a small layer: they come from a ring, with a generation check against reuse
-    while a backward is still outstanding."""
+    host time than the launches of a small layer: they come from a ring.  An entry whose previous holder is still alive
+    (its backward has not run: more than KMAX_RING PDE-layer calls outstanding — long step groups, activation
+    checkpointing, many layers) is left alone and the call gets a buffer and an event of its own instead."""
+    if n > L.PDE_MAX_SWEEPS * 4:
+        raise L.PdeError(f"{n} coefficient maxima exceed the ring entry of {L.PDE_MAX_SWEEPS * 4}")
     dev = torch.cuda.current_device()
-    ring = _kmax_rings.get(dev)
-    if ring is None:
-        pool = torch.empty(KMAX_RING * L.PDE_MAX_SWEEPS * 4, dtype=torch.float32, pin_memory=True)
-        ring = _kmax_rings[dev] = {"next": 0, "entries": []}
-        for i in range(KMAX_RING):
+    with _kmax_lock:                                       # autograd threads of several devices, DataParallel replicas
+        ring = _kmax_rings.get(dev)
+        if ring is None:
+            pool = torch.empty(KMAX_RING * L.PDE_MAX_SWEEPS * 4, dtype=torch.float32, pin_memory=True)
+            ring = {"next": 0, "entries": []}
+            for i in range(KMAX_RING):
+                e = _KmaxEntry()
+                e.host = pool[i * L.PDE_MAX_SWEEPS * 4:(i + 1) * L.PDE_MAX_SWEEPS * 4]
+                e.event = torch.cuda.Event()
+                e.event.record()        # creates the underlying hipEvent_t; the library re-records it
+                e.gen = 0
+                e.owner = None
+                ring["entries"].append(e)
+            _kmax_rings[dev] = ring
+        e = ring["entries"][ring["next"]]
+        if e.owner is not None and e.owner() is not None:  # still held by a call whose backward is outstanding
             e = _KmaxEntry()
-            e.host = pool[i * L.PDE_MAX_SWEEPS * 4:(i + 1) * L.PDE_MAX_SWEEPS * 4]
+            e.host = torch.empty(L.PDE_MAX_SWEEPS * 4, dtype=torch.float32, pin_memory=True)
             e.event = torch.cuda.Event()
-            e.event.record()            # creates the underlying hipEvent_t; the library re-records it
+            e.event.record()
             e.gen = 0
-            ring["entries"].append(e)
-    e = ring["entries"][ring["next"]]
-    ring["next"] = (ring["next"] + 1) % KMAX_RING
-    e.gen += 1
-    if n > e.host.numel():
-        raise L.PdeError(f"{n} coefficient maxima exceed the ring entry of {e.host.numel()}")
-    return _KmaxTicket(e, n)
+        else:
+            ring["next"] = (ring["next"] + 1) % KMAX_RING
+        e.gen += 1
+        t = _KmaxTicket(e, n)
+        e.owner = weakref.ref(t)
+    return t
 
 
 class _KmaxOwned:
@@ -243,7 +261,7 @@ def _wait_event(ev, spins=4000):
 
 class _KmaxTicket:
     """One use of a ring entry: ``host`` / ``event`` as long as the entry has not been handed out again."""
-    __slots__ = ("entry", "gen", "n")
+    __slots__ = ("entry", "gen", "n", "__weakref__")
 
     def __init__(self, entry, n):
         self.entry, self.gen, self.n = entry, entry.gen, n
@@ -504,6 +522,10 @@ class _AdiMultiFn(torch.autograd.Function):
         u = u.contiguous()
         need_grad = any(ctx.needs_input_grad)
         want_kmax = need_grad and ckpt == "auto"
+        if ckpt != "auto" and not isinstance(ckpt, (tuple, list)):
+            ckpt = (int(ckpt),) * nl                      # one step-local mask for every layer
+        if ckpt != "auto" and len(ckpt) != nl:
+            raise L.PdeError(f"adi_diffuse_multi: {len(ckpt)} checkpoint masks for {nl} layers")
         ctx.ckpt = ckpt
         ctx.set_materialize_grads(False)
         wdev = None if weights is None else weights.detach().to(torch.float32).contiguous()   # read by the kernels on the device
@@ -543,7 +565,14 @@ class _AdiMultiFn(torch.autograd.Function):
             ev = keep[-1][5].event if want_kmax else None      # recorded behind the last layer's copy
             L.check(lib.pde_adi_multi_forward(nl, arr, _ptr(u), _ptr(out), C.c_void_p(ev.cuda_event if ev is not None else 0),
                                               _stream()), "pde_adi_multi_forward")
-        ctx.keep, ctx.descs, ctx.per, ctx.u, ctx.wdev = keep, descs, per, u, wdev
+        # the input, the parameter views and the operators go through save_for_backward (an in-place change of any of them
+        # between forward and backward then raises torch's version-counter error instead of giving gradients that mix the
+        # forward's factorisation with new parameter values); workspaces, states and tickets stay on ctx
+        saved = [u] + ([wdev] if wdev is not None else [])
+        for k in keep:
+            saved += list(k[0]) + [k[1]]
+        ctx.save_for_backward(*saved)
+        ctx.keep, ctx.descs, ctx.per = [k[2:] for k in keep], descs, per
         ctx.has_w = weights is not None
         ctx.want_sums = want_sums
         ys = [k[3][-1] for k in keep]                      # the last sweep output of every layer
@@ -554,15 +583,19 @@ class _AdiMultiFn(torch.autograd.Function):
         lib = L.load()
         nl = len(ctx.per)
         gys, gsums = gall[:nl], (gall[nl:] if ctx.want_sums else (None,) * nl)
-        u = ctx.u
+        saved = ctx.saved_tensors
+        u = saved[0]
+        wdev = saved[1] if ctx.has_w else None
+        pm = saved[2 if ctx.has_w else 1:]                 # per layer: four parameter views and the operator
         B, Cc, N, _ = u.shape
         arr = (L.PdeSmallLayer * nl)()
         if ctx.ckpt == "auto":
-            _wait_event(ctx.keep[-1][5].event)
+            _wait_event(ctx.keep[-1][3].event)
         outs, hold = [], []
         gout_c = None if gout is None else gout.to(u.dtype).contiguous()
         for i in range(nl):
-            p, Mf, sws, states, kdev, tk = ctx.keep[i]
+            sws, states, kdev, tk = ctx.keep[i]
+            p, Mf = pm[5 * i:5 * i + 4], pm[5 * i + 4]
             sps, K, shapes, Mdt = ctx.per[i]
             d = ctx.descs[i]
             bits = 0
@@ -571,7 +604,7 @@ class _AdiMultiFn(torch.autograd.Function):
                 for k in range(K):
                     bits |= plan_checkpoints(km[k * sps:(k + 1) * sps])
             else:
-                bits = int(ctx.ckpt)
+                bits = int(ctx.ckpt[i])
             mask = (C.c_uint64 * 2)(bits & (2 ** 64 - 1), bits >> 64)
             ws = _workspace(lib.pde_adi_small_backward_workspace_bytes(C.byref(d), sps, bin(bits).count("1")), u.device)
             gp = [torch.empty_like(t) for t in p]
@@ -584,7 +617,7 @@ class _AdiMultiFn(torch.autograd.Function):
             a.M = Mf.data_ptr()
             a.alpha_base, a.beta_base, a.alpha_slope, a.beta_slope = (t.data_ptr() for t in p)
             a.weight = 0.0
-            a.weight_ptr = None if ctx.wdev is None else ctx.wdev.data_ptr() + 4 * i
+            a.weight_ptr = None if wdev is None else wdev.data_ptr() + 4 * i
             a.states = states.data_ptr()
             a.steps_workspace, a.steps_workspace_bytes = sws.data_ptr(), sws.numel()
             a.gys = gyi.data_ptr() if gyi is not None else None
@@ -614,13 +647,16 @@ def adi_diffuse_multi(u, layers, weights=None, plane_sums=False, checkpoints="au
     optionally smooth3, clamp_max, eps.  ``weights`` (L,): ``out = sum_i weights[i] * y_i`` (cifar10.py:277-280
     without the attention gates); None: ``out`` is not meaningful.  Returns ``(out, [y_1 .. y_L])``, and with
     ``plane_sums`` also ``[s_1 .. s_L]``, ``s_i[b,c] = sum_hw y_i`` — the adaptive average pool of
-    cifar10.py:239 times H*W, a by-product of the kernel (differentiable like the ``y_i``).  ``checkpoints``: "auto"
-    or one step-local bit mask for every layer (an int: no host wait at all — the call is then hipGraph-capturable)."""
+    cifar10.py:239 times H*W, a by-product of the kernel (differentiable like the ``y_i``).  ``checkpoints``: "auto",
+    one step-local bit mask for every layer (an int) or one mask per layer (a tuple) — with masks there is no host wait
+    at all and the call is hipGraph-capturable."""
     specs = tuple((_as_schedule(ly["steps"]), bool(ly.get("smooth3", False)), ly.get("clamp_max"),
                    float(ly.get("eps", 1e-6))) for ly in layers)
     flat = []
     for ly in layers:
         flat += [ly["alpha_base"], ly["beta_base"], ly["alpha_time_coeff"], ly["beta_time_coeff"], ly["M"]]
+    if isinstance(checkpoints, list):
+        checkpoints = tuple(checkpoints)
     res = _AdiMultiFn.apply(u, weights, specs, bool(plane_sums), checkpoints, *flat)
     nl = len(layers)
     if plane_sums:

@@ -80,44 +80,68 @@ class _AdiBase(nn.Module):
         cache = self.__dict__.setdefault("_kmax_cache", {})
         old = cache.get(key)
         if old is None:
-            cache.clear()
+            for k in [k for k in cache if k[-5:] != key[-5:]]:      # plans made for another dt/dx/dy/num_steps/device
+                del cache[k]
             km = F_.kappa_max_async(u, *args, flat, **kw)
             km.event.synchronize()
             old = (km, plan(km.host.tolist()))
         elif old[0].event.query():
             old = (old[0], plan(old[0].host.tolist()))
-        seen = self.__dict__.get("_plans_seen")
-        if seen is not None:                                 # freeze_checkpoint_plan() is listening
-            seen.append(old[1])
         return old, cache, key
 
-    def freeze_checkpoint_plan(self, example):
-        """Pin the checkpoint plan to an explicit mask made from the CURRENT parameters (one synchronous wait; the
-        conservative budget of the lagged policy).  A call with an explicit mask issues launches only — no wait
-        for the coefficient maxima, no host copy — which is what hipGraph capture needs (``graphs.py``).  The mask
-        stays valid while the coefficients do not grow by more than the budget's margin (a factor 2 in error
-        amplification); call again after large parameter changes.  ``example``: a tensor like the layer's input."""
-        self.__dict__.pop("_kmax_cache", None)
-        seen = self.__dict__["_plans_seen"] = []
-        old = self.checkpoint_policy
-        self.checkpoint_policy = "lagged"
-        try:
-            with torch.enable_grad():
-                self(example.detach().clone().requires_grad_(True))
-        finally:
-            self.checkpoint_policy = old
-            self.__dict__.pop("_plans_seen", None)
-            self.__dict__.pop("_kmax_cache", None)
-        mask = 0
-        for m in seen:
-            mask |= int(m)
-        self.checkpoint_policy = mask
-        return mask
+    def _uses_operator(self):
+        """Whether the layer runs a channel operator between its steps (then checkpoint masks are step-local)."""
+        return False
 
-    def _diffuse(self, u, sweeps):
+    def _step_groups(self, steps):
+        per = max(1, L.PDE_MAX_SWEEPS // len(steps[0]))
+        return [steps[i:i + per] for i in range(0, len(steps), per)]
+
+    def freeze_checkpoint_plan(self, example=None):
+        """Pin the checkpoint plan to explicit masks made from the CURRENT parameters alone — one small kernel and one
+        synchronous wait per group of steps, no forward pass of the layer (nothing else in the model runs, no BatchNorm
+        statistics move, no random numbers are drawn); the conservative budget of the lagged policy.  A call with explicit
+        masks issues launches only — no wait for the coefficient maxima, no host copy — which is what hipGraph capture needs
+        (``graphs.py``).  The masks stay valid while the coefficients do not grow by more than the budget's margin (a factor
+        2 in error amplification); call again after large parameter changes.  ``example`` is accepted for compatibility and
+        ignored.  Returns the mask (an int) or, for schedules that run as several launch groups, one mask per group."""
+        ab = self.alpha_base
+        Cc, N = (1, ab.shape[-1]) if ab.dim() == 2 else (ab.shape[0], ab.shape[-1])
+        like = torch.empty((1, Cc, N, N), dtype=torch.float32, device=ab.device)
         args = (self.alpha_base, self.beta_base, self.alpha_time_coeff, self.beta_time_coeff)
         kw = dict(smooth3=self._smooth3, clamp_max=self._clamp_max, eps=self.stability_eps)
+        masks = []
+        with torch.no_grad():
+            for grp in self._step_groups(self._schedule()):
+                sps = len(grp[0])
+                km = F_.kappa_max_async(like, *args, [s for st in grp for s in st], **kw)
+                km.event.synchronize()
+                v = km.host.tolist()
+                if self._uses_operator():
+                    bits = 0
+                    for k in range(len(grp)):
+                        bits |= F_.plan_checkpoints(v[k * sps:(k + 1) * sps], F_.CKPT_AMAX / 2)
+                else:
+                    bits = F_.plan_checkpoints(v, F_.CKPT_AMAX / 2)
+                masks.append(int(bits))
+        self.__dict__.pop("_kmax_cache", None)
+        self.checkpoint_policy = masks[0] if len(masks) == 1 else tuple(masks)
+        return self.checkpoint_policy
+
+    def _policy_of_group(self, gi, num_sweeps=None):
+        """The checkpoint policy of launch group ``gi``: a frozen plan is one mask per group; a single mask given for a
+        schedule of several groups keeps the bits the group's own schedule has (a plain group of S sweeps: bits 0..S-2)."""
         ck = self.checkpoint_policy
+        if isinstance(ck, (tuple, list)):
+            ck = ck[gi]
+        if isinstance(ck, int) and not isinstance(ck, bool) and num_sweeps is not None:
+            ck &= (1 << max(num_sweeps - 1, 0)) - 1
+        return ck
+
+    def _diffuse(self, u, sweeps, gi=0):
+        args = (self.alpha_base, self.beta_base, self.alpha_time_coeff, self.beta_time_coeff)
+        kw = dict(smooth3=self._smooth3, clamp_max=self._clamp_max, eps=self.stability_eps)
+        ck = self._policy_of_group(gi, len(sweeps))
         if not (torch.is_grad_enabled() and (u.requires_grad or any(p.requires_grad for p in args))):
             ck = 0
         if ck != "lagged":
@@ -138,15 +162,15 @@ class _AdiBase(nn.Module):
                 return self._diffuse(u, steps.flat if isinstance(steps, F_.Schedule) else [s for st in steps for s in st])
             return self._diffuse_mixed(u, steps, M, mode, skip_weight)
         u0 = u
-        for i in range(0, len(steps), per):
-            grp = steps[i:i + per]
-            u = self._diffuse(u, [s for st in grp for s in st]) if M is None else self._diffuse_mixed(u, grp, M, mode)
+        for gi, grp in enumerate(self._step_groups(steps)):
+            u = (self._diffuse(u, [s for st in grp for s in st], gi) if M is None
+                 else self._diffuse_mixed(u, grp, M, mode, gi=gi))
         return u if skip_weight is None else F_.skip_blend(u0, u, skip_weight)
 
     #: False forces the per-step launch path (pde_adi_mixed_*) where the single-launch C <= 4 kernels would apply
     small_channel_kernels = True
 
-    def _diffuse_mixed(self, u, steps, M, mode, skip_weight=None):
+    def _diffuse_mixed(self, u, steps, M, mode, skip_weight=None, gi=0):
         """All steps of a layer with a channel operator between them; checkpoints as in ``_diffuse`` (one step-local
         mask for every step).  C <= 4 (the reference's own models): the whole time loop — and for SVHN the skip
         blend — in one launch per pass (functional.adi_diffuse_small); otherwise one mixing and one sweep launch per
@@ -162,7 +186,7 @@ class _AdiBase(nn.Module):
             y = F_.adi_diffuse_mixed(u, *args, M, steps, mode, checkpoints=ck, kmax_sink=sink, **kw)
             return y if skip_weight is None else F_.skip_blend(u_in, y, skip_weight)          # SVHN.py:73-74
 
-        ck = self.checkpoint_policy
+        ck = self._policy_of_group(gi)
         live = (M, skip_weight) + args
         if not (torch.is_grad_enabled() and (u.requires_grad or any(p is not None and p.requires_grad for p in live))):
             ck = 0
@@ -248,6 +272,9 @@ class SvhnDiffusionLayer(_AdiBase):
         self.stability_eps = 1e-6
         self.skip_weight = nn.Parameter(torch.tensor(0.9))
 
+    def _uses_operator(self):
+        return True
+
     def forward(self, u):
         # SVHN.py:55-76: sweeps, coupling after every step, then sigmoid(w) u0 + (1 - sigmoid(w)) u
         return self._run(u, self._schedule(), self.channel_coupling, "post", self.skip_weight)
@@ -280,6 +307,9 @@ class EnhancedDiffusionLayer(_AdiBase):
         print(f"  Temporal: dt={self.dt}, steps={self.num_steps}")
         print(f"  Learnable parameters: α matrices ({self.channels}x{self.size}x{self.size}), "
               f"β matrices ({self.channels}x{self.size}x{self.size})")
+
+    def _uses_operator(self):
+        return bool(self.channel_mixing_enabled)
 
     def forward(self, u):
         steps = self._schedule()

@@ -44,7 +44,8 @@ def diffuse_shared_input(layers, x, weights=None, plane_sums=False):
     same_split = len({len(st[0]) for st in steps}) == 1
     fused = (same_split and len(layers) <= 4 and x.is_cuda and all(getattr(ly, "channel_mixing_enabled", True) for ly in layers)
              and all(ly.small_channel_kernels and ly.checkpoint_policy != "lagged" for ly in layers)
-             and len({str(ly.checkpoint_policy) for ly in layers}) == 1
+             and (all(ly.checkpoint_policy == "auto" for ly in layers)
+                  or all(isinstance(ly.checkpoint_policy, int) for ly in layers))          # frozen masks may differ per layer
              and all(F_.adi_small_supported(x, st, smooth3=ly._smooth3, clamp_max=ly._clamp_max, eps=ly.stability_eps)
                      for ly, st in zip(layers, steps)))
     if not fused:
@@ -54,7 +55,8 @@ def diffuse_shared_input(layers, x, weights=None, plane_sums=False):
     descr = [dict(alpha_base=ly.alpha_base, beta_base=ly.beta_base, alpha_time_coeff=ly.alpha_time_coeff,
                   beta_time_coeff=ly.beta_time_coeff, M=ly.channel_mixing, steps=st, smooth3=ly._smooth3,
                   clamp_max=ly._clamp_max, eps=ly.stability_eps) for ly, st in zip(layers, steps)]
-    res = F_.adi_diffuse_multi(x, descr, weights, plane_sums, layers[0].checkpoint_policy)
+    pol = layers[0].checkpoint_policy
+    res = F_.adi_diffuse_multi(x, descr, weights, plane_sums, pol if pol == "auto" else tuple(int(ly.checkpoint_policy) for ly in layers))
     out = res[0] if weights is not None else None
     return (out, res[1], res[2]) if plane_sums else (out, res[1])
 

@@ -36,6 +36,9 @@ class Golden:
         self.params = {k[6:]: t(z[k]) for k in z.files if k.startswith("param_")}
         self.grads = {k[5:]: t(z[k]) for k in z.files if k.startswith("grad_")}
         self.grad_is_none = {k[9:]: bool(z[k]) for k in z.files if k.startswith("gradnone_")}
+        # model fixtures that hold buffers: before the forward, and what one forward left in them (training mode)
+        self.bufin = {k[6:]: t(z[k]) for k in z.files if k.startswith("bufin_")}
+        self.bufout = {k[7:]: t(z[k]) for k in z.files if k.startswith("bufout_")}
         self.script, self.cls, self.ctor = self.meta["script"], self.meta["cls"], self.meta["ctor"]
 
     # -- mapping onto the oracle -------------------------------------------------

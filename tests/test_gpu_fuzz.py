@@ -98,11 +98,18 @@ def test_random_case_vs_oracle(case):
         if p.requires_grad:
             errs["g_" + n] = G.rel_err(p.grad.cpu().reshape(gp_ref[n].shape), gp_ref[n])
     # Parameters of a handful of entries (skip_weight; the operator at C <= 2) are sums of B*C*N*N signed terms that
-    # largely cancel: their rounding noise relative to the sum itself passes 1e-5 now and then on small tensors (1.1e-5
-    # and 1.02e-5 seen in 800 walked cases); 1e-4 for those — the class of the stated deviations in DESIGN.md §5 —,
-    # 1e-5 everywhere else
-    small = {"g_" + n for n, v in gp_ref.items() if v.numel() <= 4}
-    bad = {k: v for k, v in errs.items() if not v <= (1e-4 if k in small else 1e-5)}
+    # largely cancel, so the fp32 ORACLE's own rounding noise relative to the sum passes 1e-5 now and then (two of 800
+    # walked cases: 1.02e-5 and 1.13e-5).  Those gradients are therefore decided against the oracle evaluated in fp64
+    # (the same restatement on .double() inputs), at 2e-5; everything else against the fp32 oracle at 1e-5.
+    small = {n for n, v in gp_ref.items() if v.numel() <= 4}
+    if small:
+        p64 = {k: v.double() for k, v in params.items()}
+        _, _, gp64 = O.value_and_grads(lambda a, p: O.adi_forward(a, p, spec), u.double(), p64, gy.double())
+        for n in small:
+            errs["g_" + n] = G.rel_err(dl.get_parameter(n).grad.cpu().reshape(gp64[n].shape), gp64[n])
+            errs["oracle32_vs_64_" + n] = G.rel_err(gp_ref[n], gp64[n])           # reported with a failure: which side is noisy
+    limit = lambda k: 2e-5 if k[2:] in small else (float("inf") if k.startswith("oracle32") else 1e-5)
+    bad = {k: v for k, v in errs.items() if not v <= limit(k)}
     assert not bad, (bad, errs)
 
 

@@ -80,6 +80,10 @@ def test_graphed_step_of_the_shared_input_layers():
             layers[1].alpha_base.mul_(1.1)
 
 
+# (torch.cuda.make_graphed_callables warms the module up on a side stream and keeps those AccumulateGrad nodes of the
+# parameters alive inside its own graphed autograd function: the stream-mismatch warning of the eager backward below is
+# torch's, about torch's nodes — this package's GraphedStep keeps no autograd graph, see graphs.py)
+@pytest.mark.filterwarnings("ignore:The AccumulateGrad node's stream does not match")
 def test_make_graphed_layer_trains_like_the_eager_one():
     import cnn_with_pde_amd as P
     g = torch.Generator().manual_seed(5)
@@ -135,3 +139,107 @@ def test_graphed_step_of_a_wide_layer(kind):
     torch.cuda.synchronize()
     for a, b in zip(got, eager):
         assert torch.equal(a, b)
+
+
+def test_freezing_plans_has_no_side_effects():
+    """The plans come from the parameters alone: no forward pass of the model, so BatchNorm running statistics and
+    num_batches_tracked stay where they are (graphs.py ran an eager training-mode forward)."""
+    import cnn_with_pde_amd as P
+    model = quiet(P.CIFAR10PDENoConv).cuda().train()
+    before = {n: b.clone() for n, b in model.named_buffers()}
+    state = torch.cuda.get_rng_state()
+    P.freeze_checkpoint_plans(model)
+    assert torch.equal(state, torch.cuda.get_rng_state())
+    for n, b in model.named_buffers():
+        assert torch.equal(b, before[n]), n
+
+
+def test_shared_input_layers_with_different_frozen_masks_stay_fused():
+    """Three mixing-first layers on one input whose frozen masks DIFFER (different coefficient sizes): still one launch per
+    pass (per-layer masks reach pde_adi_multi_*), capturable, and bitwise the automatic plan's result."""
+    import cnn_with_pde_amd as P
+    from cnn_with_pde_amd import functional as F_
+    g = torch.Generator().manual_seed(21)
+    layers = [quiet(P.EnhancedDiffusionLayer, 32, 3, dt=0.001, num_steps=4).cuda(),
+              quiet(P.EnhancedDiffusionLayer, 32, 3, dt=0.6, num_steps=4).cuda(),
+              quiet(P.EnhancedDiffusionLayer, 32, 3, dt=0.6, num_steps=4).cuda()]
+    with torch.no_grad():
+        layers[2].alpha_base.mul_(6.0)                           # larger coefficients along x only: another plan
+    x = torch.randn(5, 3, 32, 32, generator=g).cuda().requires_grad_(True)
+    gy = torch.randn(5, 3, 32, 32, generator=g).cuda()
+    w = torch.tensor([0.5, 0.3, 0.2], device="cuda", requires_grad=True)
+    params = [p for ly in layers for p in ly.parameters()]
+
+    def fn():
+        out, _ = P.diffuse_shared_input(layers, x, w)
+        return (out,) + torch.autograd.grad(out, [x, w] + params, gy)
+    auto = [t.detach().clone() for t in fn()]            # (no grad_fn kept: a live autograd graph of the default stream
+                                                         #  would drag that stream into the capture below — torch's warning)
+    masks = [ly.freeze_checkpoint_plan() for ly in layers]
+    assert masks[0] == 0 and masks[1] != 0 and masks[2] != masks[1], masks
+    calls = []
+    orig = F_.adi_diffuse_multi
+    F_.adi_diffuse_multi = lambda *a, **k: (calls.append(a[4] if len(a) > 4 else k.get("checkpoints")), orig(*a, **k))[1]
+    try:
+        step = P.GraphedStep(fn)
+    finally:
+        F_.adi_diffuse_multi = orig
+    assert calls and all(c == tuple(masks) for c in calls), calls      # the fused entry point, with one mask per layer
+    got = step()
+    torch.cuda.synchronize()
+    for a, b in zip(got, auto):
+        assert G.rel_err(a.cpu(), b.cpu()) <= 1e-5
+
+
+def test_long_schedule_freezes_one_mask_per_launch_group():
+    """num_steps > 32 Strang steps run as several launch groups (PDE_MAX_SWEEPS = 96): a frozen plan is one mask per group
+    (the tail group is shorter: a single union mask would carry bits beyond its schedule), and a single int mask given
+    by hand is cut to each group's own bits."""
+    import cnn_with_pde_amd as P
+    from oracle import pde_oracle as O
+    g = torch.Generator().manual_seed(4)
+    layer = quiet(P.MnistDiffusionLayer, 12, dt=0.2, dx=1.0, dy=1.0, num_steps=35)
+    with torch.no_grad():
+        layer.alpha_base.mul_(0.7 + 0.3 * torch.rand(12, 12, generator=g))
+    u = torch.randn(3, 1, 12, 12, generator=g)
+    gy = torch.randn(3, 1, 12, 12, generator=g)
+    spec = O.mnist_spec(12, 0.2, 1.0, 1.0, 35)
+    params = {k: v.detach().clone() for k, v in layer.named_parameters()}
+    y_ref, gu_ref, gp_ref = O.value_and_grads(lambda a, p: O.adi_forward(a, p, spec), u, params, gy)
+    dl = layer.cuda()
+    masks = dl.freeze_checkpoint_plan()
+    assert isinstance(masks, tuple) and len(masks) == 2 and masks[0] != 0 and masks[1] != 0
+    assert masks[1] < (1 << 8)                                   # the tail group has 3 steps = 9 sweeps: bits 0..7
+    for policy in (masks, "auto", "lagged", masks[0]):           # masks[0] (32-step plan) on both groups: cut to the tail's bits
+        dl.checkpoint_policy = policy
+        got = _grads(dl, u.cuda(), gy.cuda())
+        errs = [G.rel_err(got[0].cpu(), y_ref), G.rel_err(got[1].cpu(), gu_ref)]
+        errs += [G.rel_err(a.cpu(), gp_ref[n]) for a, (n, _) in zip(got[2:], dl.named_parameters())]
+        assert max(errs) <= 1e-5, (policy, errs)
+
+
+def test_more_outstanding_forwards_than_ring_entries():
+    """More PDE-layer forwards outstanding than the coefficient-maxima ring has entries (functional.KMAX_RING): the extra
+    calls get buffers of their own instead of raising in the backward."""
+    import cnn_with_pde_amd as P
+    from cnn_with_pde_amd import functional as F_
+    layer = quiet(P.EnhancedDiffusionLayer, 8, 2, dt=0.01, num_steps=1, channel_mixing_enabled=False).cuda()
+    u = torch.randn(1, 2, 8, 8, device="cuda", requires_grad=True)
+    outs = [layer(u) for _ in range(F_.KMAX_RING + 40)]
+    torch.stack([o.sum() for o in outs]).sum().backward()
+    torch.cuda.synchronize()
+    one = torch.autograd.grad(layer(u).sum(), u)[0]
+    assert G.rel_err(u.grad.cpu(), (one * len(outs)).cpu()) <= 1e-5
+
+
+def test_shared_input_backward_notices_in_place_changes():
+    """The fused shared-input call saves its input and parameters through save_for_backward: changing a parameter in place
+    between forward and backward raises instead of mixing the forward's factorisation with new values."""
+    import cnn_with_pde_amd as P
+    layers = [quiet(P.EnhancedDiffusionLayer, 32, 3, dt=0.001, num_steps=2).cuda() for _ in range(2)]
+    x = torch.randn(2, 3, 32, 32, device="cuda", requires_grad=True)
+    out, _ = P.diffuse_shared_input(layers, x, torch.tensor([0.5, 0.5], device="cuda"))
+    with torch.no_grad():
+        layers[0].alpha_base.mul_(1.5)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        out.sum().backward()

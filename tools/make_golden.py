@@ -164,6 +164,26 @@ def models():
     make_model("model_cifar2_hybrid_8", "cifar_2version", "HybridPDEExtractor", {"input_size": 8, "channels": 3},
                (4, 3, 8, 8), 83, tweak=live2)
 
+    # the whole cifar10.CIFAR10PDENoConv (cifar10.py:318-361): extractor + BatchNorm2d + 4x4 average / max pooling + classifier,
+    # in training mode (batch statistics; dropout rate 0 through the constructor so that the pass is deterministic) and in eval
+    # mode, BatchNorm parameters and running statistics away from their initial values
+    def noconv(m, g):
+        live(m, g)
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                if n == "feature_bn.weight":
+                    p.copy_(1 + 0.3 * torch.randn(p.shape, generator=g))
+                elif n == "feature_bn.bias":
+                    p.copy_(0.2 * torch.randn(p.shape, generator=g))
+            for n, b in m.named_buffers():
+                if n.endswith("running_mean"):
+                    b.copy_(0.1 * torch.randn(b.shape, generator=g))
+                elif n.endswith("running_var"):
+                    b.copy_(0.5 + torch.rand(b.shape, generator=g))
+    make_model("model_cifar10_noconv_train", "cifar10", "CIFAR10PDENoConv", {"dropout_rate": 0.0}, (6, 3, 32, 32), 84,
+               tweak=noconv, eval_mode=False, buffers=True)
+    make_model("model_cifar10_noconv_eval", "cifar10", "CIFAR10PDENoConv", {}, (3, 3, 32, 32), 85, tweak=noconv, buffers=True)
+
     # the Ruthotto-Haber blocks alone (cifar_2version.py:190-258) at 8x8 (K is 192^2), training mode (batch statistics,
     # running statistics updated) and eval mode (running statistics), BatchNorm affine parameters and running
     # statistics away from their initial values
