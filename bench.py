@@ -54,13 +54,21 @@ def build_layer(C, N, steps, dev, rank, mixing):
 
 def run_steps(layer, u, gy, n, dist_on, flat):
     for _ in range(n):
-        for p in layer.parameters():
-            p.grad = None
+        if dist_on:
+            flat.zero()                         # the gradients are views of the flat bucket: one launch clears them
+        else:
+            for p in layer.parameters():
+                p.grad = None
         u.grad = None
         y = layer(u)
         y.backward(gy)
         if dist_on:
-            flat.allreduce(average=True)        # one flat bucket (1.06 MB): latency-bound over xGMI
+            # one flat bucket (1.06 MB, latency-bound over xGMI).  Headline: the collective was launched from inside
+            # backward by the bucket's hooks (ReduceOp.AVG: no separate division), finish() only waits for it; the other
+            # legs (some of their parameters receive no gradient) launch it here.
+            if not flat._hooks:
+                flat.start(average=True)
+            flat.finish()
 
 
 def timed(layer, u, gy, steps, warmup, dist_on, flat):
@@ -161,7 +169,7 @@ def config_legs(dev, rank, world, dist_on, quick):
         g = torch.Generator().manual_seed(4321 + rank)
         u = torch.randn(*shape, generator=g).to(dtype).to(dev).requires_grad_(True)
         gy = torch.randn(*shape, generator=g).to(dtype).to(dev)
-        flat = P.GradBucket(layer.parameters()) if dist_on else None
+        flat = P.GradBucket(layer.parameters(), grads_as_views=True) if dist_on else None
         dt = timed(layer, u, gy, steps, 10, dist_on, flat)      # the small legs are host-bound: let clocks and caches settle
         ms = dt / steps * 1e3
         gbs = u.numel() * bpe / (dt / steps) / 1e9            # per GPU
@@ -384,7 +392,10 @@ def main():
     gy = torch.randn(B, C, N, N, generator=g).to(dev)
     layer = build_layer(C, N, steps, dev, rank, mixing=False)
     layer.channel_mixing.requires_grad_(False)          # unused when mixing is disabled
-    flat = P.GradBucket(layer.parameters()) if dist_on else None
+    flat = None
+    if dist_on:
+        flat = P.GradBucket(layer.parameters(), grads_as_views=True)
+        flat.attach_hooks(average=True)         # the all-reduce leaves from inside backward, behind the last gradient
 
     dt = timed(layer, u, gy, a.steps, a.warmup, dist_on, flat)
     ms_step = dt / a.steps * 1e3
@@ -490,7 +501,7 @@ def main():
 
     if not a.no_secondary:
         layer2 = build_layer(C, N, steps, dev, rank, mixing=True)
-        flat2 = P.GradBucket(layer2.parameters()) if dist_on else None
+        flat2 = P.GradBucket(layer2.parameters(), grads_as_views=True) if dist_on else None
         k2 = max(3, a.steps // 5)
         dt2 = timed(layer2, u, gy, k2, 2, dist_on, flat2)
         if rank == 0:

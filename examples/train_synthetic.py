@@ -5,7 +5,8 @@ Counterpart of the reference's training entry points (model shape of mnist_test.
 the optimiser recipe of mnist_test.py:282-306: AdamW, cosine schedule, label smoothing, grad clipping),
 with the diffusion layer taken from this package and data parallelism over RCCL:
 
-    python examples/train_synthetic.py --variant mnist --steps 200
+    python examples/train_synthetic.py --variant mnist --steps 200        # single GPU, fp32: the step is ONE hipGraph
+    python examples/train_synthetic.py --variant mnist --steps 200 --eager  # the same, one eager autograd step at a time
     python examples/train_synthetic.py --variant cifar10_noconv --amp          # cifar10.py:318-361 under fp16 autocast
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
         examples/train_synthetic.py --variant svhn_model --steps 200
@@ -107,7 +108,7 @@ def train_graphed(a, model, templates, classes, crit, gen, dev):
         return loss, out
 
     def capture():
-        plans = P.freeze_checkpoint_plans(model, static_x)
+        plans = P.freeze_checkpoint_plans(model)           # from the parameters alone: no forward pass, no side effects
         state["plans"] = {id(k): v for k, v in plans.items()}
         state["step"] = P.GraphedStep(one_step)
 
@@ -128,7 +129,7 @@ def train_graphed(a, model, templates, classes, crit, gen, dev):
             acc = (out.argmax(1) == static_y).float().mean().item()
             log.append({"step": step, "loss": round(loss.item(), 4), "acc": round(acc, 3)})
             print(f"step {step:5d}  loss {loss.item():.4f}  acc {acc:.3f}", flush=True)
-            now = {id(k): v for k, v in P.freeze_checkpoint_plans(model, static_x).items()}
+            now = {id(k): v for k, v in P.freeze_checkpoint_plans(model).items()}
             if now != state["plans"]:                      # coefficients grew past the frozen plan's margin
                 capture()
                 recaptures += 1
@@ -149,7 +150,10 @@ def main():
     ap.add_argument("--log-every", type=int, default=50)
     ap.add_argument("--graph", action="store_true",
                     help="capture the whole training step (forward, loss, backward, clipping, AdamW) in a hipGraph and replay "
-                         "it; checkpoint plans frozen and re-checked every --log-every steps (single GPU, fp32)")
+                         "it; checkpoint plans frozen and re-checked every --log-every steps.  This is the DEFAULT for a "
+                         "single-GPU fp32 run (the reference's own shapes are bound by the host's launch path when run "
+                         "eagerly: 1.8-2.4x fewer samples per second)")
+    ap.add_argument("--eager", action="store_true", help="one eager autograd step per iteration (always with --amp or several ranks)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -179,9 +183,9 @@ def main():
     bucket = P.GradBucket(model.parameters()) if world > 1 else None
     gen = torch.Generator(device=dev).manual_seed(1000 + rank)          # a different shard per rank
 
-    if a.graph:
-        if world > 1 or a.amp:
-            raise SystemExit("--graph: single GPU, fp32")
+    if a.graph and (world > 1 or a.amp):
+        raise SystemExit("--graph: single GPU, fp32")
+    if a.graph or not (a.eager or world > 1 or a.amp):
         return train_graphed(a, model, templates, classes, crit, gen, dev)
 
     log, t0 = [], time.perf_counter()

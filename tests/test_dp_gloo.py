@@ -1,4 +1,4 @@
-"""Multi-process data parallelism on CPU (gloo, world_size 2): sharding + one flat gradient
+"""Multi-process data parallelism on CPU (gloo, world_size 2 and 4): sharding + one flat gradient
 all-reduce reproduces the single-process full-batch gradients.  The compute stand-in is the oracle
 (tests may use it); the pieces under test are cnn_with_pde_amd.dist.shard_batch / GradBucket, which
 are exactly what bench.py and a DP training loop use on the GPUs."""
@@ -66,3 +66,61 @@ def test_two_rank_allreduce_matches_full_batch():
     (O.adi_forward(u, params, spec) * gy).sum().div(6).backward()
     for k, v in params.items():
         assert torch.allclose(got[k], v.grad, rtol=1e-5, atol=1e-7), k
+
+
+def _worker4(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from oracle import pde_oracle as O
+    import cnn_with_pde_amd as P
+    spec = O.cifar10_spec(8, 2, dt=0.05, num_steps=2)
+    g = torch.Generator().manual_seed(12)
+    params = {k: torch.nn.Parameter(v) for k, v in O.adi_init_params(spec, "cifar10", gen=g).items()}
+    B = 7                                                       # ragged: shards of 2, 2, 2, 1
+    u = torch.randn(B, 2, 8, 8, generator=g)
+    gy = torch.randn(B, 2, 8, 8, generator=g)
+    ul, gl = P.shard_batch(u), P.shard_batch(gy)
+    assert ul.shape[0] == (2 if rank < 3 else 1)
+    # gradients as views of the flat buffer, the collective launched from inside backward by the hooks; per-rank losses
+    # are SUMS over the shard (ragged shards), so the ranks' gradients are summed, not averaged
+    bucket = P.GradBucket(params.values(), grads_as_views=True)
+    bucket.attach_hooks(average=False)
+    res = []
+    for it in range(2):                                         # twice: the arrival counter and the views survive a step
+        bucket.zero()
+        y = O.adi_forward(ul, params, spec)
+        (y * gl).sum().backward()
+        bucket.finish()
+        res.append({k: v.grad.clone() for k, v in params.items()})
+        assert all(v.grad.data_ptr() == w.data_ptr() for v, w in zip(params.values(), bucket._views()))
+    if rank == 0:
+        q.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_four_ranks_ragged_batch_sum_semantics_views_and_hooks():
+    from oracle import pde_oracle as O
+    world, port = 4, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker4, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    spec = O.cifar10_spec(8, 2, dt=0.05, num_steps=2)
+    g = torch.Generator().manual_seed(12)
+    params = {k: v.clone().requires_grad_(True) for k, v in O.adi_init_params(spec, "cifar10", gen=g).items()}
+    u = torch.randn(7, 2, 8, 8, generator=g)
+    gy = torch.randn(7, 2, 8, 8, generator=g)
+    (O.adi_forward(u, params, spec) * gy).sum().backward()
+    for step in got:
+        for k, v in params.items():
+            assert torch.allclose(step[k], v.grad, rtol=1e-5, atol=1e-6), k
