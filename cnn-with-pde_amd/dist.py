@@ -121,7 +121,13 @@ class GradBucket:
                     op = dist.ReduceOp.AVG                    # the division inside the collective: no extra launch
                 else:
                     self._pending_div = world
-            self._work = dist.all_reduce(self.flat, op=op, group=group, async_op=True)
+            try:
+                self._work = dist.all_reduce(self.flat, op=op, group=group, async_op=True)
+            except (RuntimeError, ValueError):
+                if op == dist.ReduceOp.SUM:
+                    raise
+                self._pending_div = world                     # a backend build without AVG: sum, divide afterwards
+                self._work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
 
     def finish(self) -> None:
         """Wait for the collective launched by ``start`` (or by the hooks) and put the result where ``.grad`` is."""
