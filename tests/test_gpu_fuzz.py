@@ -98,19 +98,24 @@ def test_random_case_vs_oracle(case):
         if p.requires_grad:
             errs["g_" + n] = G.rel_err(p.grad.cpu().reshape(gp_ref[n].shape), gp_ref[n])
     # Parameters of a handful of entries (skip_weight; the operator at C <= 2) are sums of B*C*N*N signed terms that
-    # largely cancel, so the fp32 ORACLE's own rounding noise relative to the sum passes 1e-5 now and then (two of 800
-    # walked cases: 1.02e-5 and 1.13e-5).  Those gradients are therefore decided against the oracle evaluated in fp64
-    # (the same restatement on .double() inputs), at 2e-5; everything else against the fp32 oracle at 1e-5.
+    # largely cancel (seen: 2880 terms of total size 220 adding up to 0.0144), so fp32 rounding noise relative to the SUM is
+    # far above 1e-5 for the reference's own arithmetic too: on that case the fp32 oracle is 1.2e-4 away from the same
+    # restatement evaluated in fp64, the HIP result 1.9e-4.  Those gradients are therefore decided against the fp64 oracle
+    # (.double() inputs): within 2e-5 of it, or no noisier than 4x the fp32 oracle's own distance from it.  Everything
+    # else against the fp32 oracle at 1e-5.
     small = {n for n, v in gp_ref.items() if v.numel() <= 4}
+    limits = {}
     if small:
         p64 = {k: v.double() for k, v in params.items()}
         _, _, gp64 = O.value_and_grads(lambda a, p: O.adi_forward(a, p, spec), u.double(), p64, gy.double())
         for n in small:
             errs["g_" + n] = G.rel_err(dl.get_parameter(n).grad.cpu().reshape(gp64[n].shape), gp64[n])
-            errs["oracle32_vs_64_" + n] = G.rel_err(gp_ref[n], gp64[n])           # reported with a failure: which side is noisy
-    limit = lambda k: 2e-5 if k[2:] in small else (float("inf") if k.startswith("oracle32") else 1e-5)
-    bad = {k: v for k, v in errs.items() if not v <= limit(k)}
-    assert not bad, (bad, errs)
+            o32 = G.rel_err(gp_ref[n], gp64[n])
+            errs["oracle32_vs_64_" + n] = o32                                     # reported with a failure
+            limits["g_" + n] = max(2e-5, 4.0 * o32)
+            limits["oracle32_vs_64_" + n] = float("inf")
+    bad = {k: (v, limits.get(k, 1e-5)) for k, v in errs.items() if not v <= limits.get(k, 1e-5)}
+    assert not bad, (bad, {k: v for k, v in errs.items() if k.startswith("oracle32")})
 
 
 def _explicit_cases():
@@ -149,7 +154,18 @@ def test_random_explicit_case_vs_oracle(case):
     # bf16 tensors: the per-channel parameter gradients are sums over the whole batch that partly cancel, and outside
     # the plane sizes with a fused time loop the state makes a bf16 round trip per step which the oracle does not model
     ptol = tol if dtype == torch.float32 else 1e-1
-    bad = {k: v for k, v in errs.items() if not v <= (ptol if k.startswith("g_") else tol)}
+    limits = {k: (ptol if k.startswith("g_") else tol) for k in errs}
+    if dtype == torch.float32:
+        # gradients of at most four entries (C <= 4 channels: sums over the whole batch that cancel): decided against the
+        # oracle in fp64, within 2e-5 or no noisier than 4x the fp32 oracle itself — see test_random_case_vs_oracle
+        small = [n for n in params if gp_ref[n].numel() <= 4]
+        if small:
+            _, _, gp64 = O.value_and_grads(lambda a, p: O.tiny_forward(a, p, dt=dt, num_steps=steps), u.double(),
+                                           {k: v.double() for k, v in params.items()}, gy.double())
+            for n in small:
+                errs["g_" + n] = G.rel_err(getattr(dl, n).grad.float().cpu(), gp64[n])
+                limits["g_" + n] = max(2e-5, 4.0 * G.rel_err(gp_ref[n], gp64[n]))
+    bad = {k: (v, limits[k]) for k, v in errs.items() if not v <= limits[k]}
     assert not bad, (bad, errs)
 
 
