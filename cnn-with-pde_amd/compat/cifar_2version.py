@@ -1,4 +1,5 @@
-"""Drop-in for ``cifar_2version.LearnableDiffusionLayer`` of the reference."""
+"""Drop-ins for ``cifar_2version.LearnableDiffusionLayer`` and the Ruthotto-Haber blocks of the reference."""
 from ..layers import LearnableDiffusionLayer as LearnableDiffusionLayer  # noqa: F401
+from ..models import SymmetricLayer, ParabolicBlock, HamiltonianBlock  # noqa: F401
 
-__all__ = ["LearnableDiffusionLayer"]
+__all__ = ["LearnableDiffusionLayer", "SymmetricLayer", "ParabolicBlock", "HamiltonianBlock"]
