@@ -6,7 +6,8 @@
 // out = base + scale * (act(BN(X K^T)) K).  Three kernels on the fp32-input MFMAs (v_mfma_f32_16x16x4_f32 / 32x32x2_f32:
 // exact fp32 FMA chains at the fp32 vector rate, VALU left free for the epilogues):
 //
-//   strip kernel, NT  P = X K^T for ALL batch rows and a strip of 16 output features per workgroup, so the BatchNorm1d
+//   strip kernel, NT  P = X K^T for ALL batch rows (up to 128: the reference's batch; larger batches go by row blocks with the
+//                     statistics in a pass of their own) and a strip of 16 output features per workgroup, so the BatchNorm1d
 //                     statistics of a feature (over the batch) are workgroup-local and normalisation + activation are
 //                     the epilogue of the product (forward); in the backward the same product shape carries
 //                     dH = dF K^T with the activation derivative and the BatchNorm backward (two per-feature sums)
@@ -32,7 +33,6 @@ constexpr int kRhCols = 16;              // output features per strip workgroup:
 // and two of them (double buffering: one barrier per slab) fit beside each other whatever the batch
 template <int R> struct RhSlab { static constexpr int BK = 64 / R, LDA = BK + 4; };
 constexpr int kRhLdN = 20;               // LDS row stride of a [BK][16] slab (NN operand): the four k-quarters hit disjoint banks
-constexpr int kRhMaxB = 512;             // batch rows a strip workgroup can hold (4 row blocks of 16 per wave)
 
 enum { kActIdentity = 0, kActRelu = 1, kActTanh = 2 };
 
@@ -40,7 +40,7 @@ enum { kActIdentity = 0, kActRelu = 1, kActTanh = 2 };
 //   NT: Wop[k][j] = W[(n0 + j) * ldw + k]        NN: Wop[k][j] = W[k * ldw + n0 + j]
 // v_mfma_f32_16x16x4_f32: A lane l holds A[i = l & 15][k = l >> 4], B lane l holds B[k = l >> 4][j = l & 15], D lane l
 // holds rows 4 * (l >> 4) + r (r = 0..3) of column l & 15.  Wave w owns the row blocks (16 rows) w, w + 8, ... (R of
-// them).  Contraction order inside a group of 16: step s (0..3) takes k = 4 * kq + s from quarter kq = l >> 4 — one
+// them; the kernels are instantiated with R = 1: 128 batch rows per workgroup, larger batches are cut into row blocks).  Contraction order inside a group of 16: step s (0..3) takes k = 4 * kq + s from quarter kq = l >> 4 — one
 // 16-byte LDS read feeds four steps.  16 columns per workgroup instead of 32 (v_mfma_f32_32x32x2_f32) because a
 // batch of 128 is only 96 strips of 32: with 192 the product runs on three quarters of the chip instead of three eighths.
 template <int R, bool NT>
@@ -214,6 +214,14 @@ __global__ __launch_bounds__(kRhStripThreads) void rh_fwd_strip_kernel(RhFwdArgs
         }
 }
 
+struct RhBwdArgs {
+    const float* G; const float* K; const float* gamma;
+    const float* P; const float* H; const float* mean; const float* invstd;
+    float* dP; float* g_gamma; float* g_beta;
+    int B, D, act, training;
+    float scale;
+};
+
 struct RhAxpyArgs {
     const float* X; const float* K; const float* base; float* out;
     int B, D;
@@ -228,27 +236,109 @@ __global__ __launch_bounds__(kRhStripThreads) void rh_axpy_strip_kernel(RhAxpyAr
     float* Ws = As + 2 * kRhWaves * R * 16 * RhSlab<R>::LDA;             // [2][BK][20]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, jj = lane & 15, kq = lane >> 4;
     const int n0 = blockIdx.x * kRhCols, col = n0 + jj;
+    const int row0 = blockIdx.y * (kRhWaves * R * 16);    // row block of this workgroup (rows are independent here)
+    const int rows = a.B - row0 < kRhWaves * R * 16 ? a.B - row0 : kRhWaves * R * 16;
     f32x4 acc[R];
-    strip_gemm<R, false>(a.X, a.B, a.D, a.D, a.K, a.D, n0, acc, As, Ws);
+    strip_gemm<R, false>(a.X + (size_t)row0 * a.D, rows, a.D, a.D, a.K, a.D, n0, acc, As, Ws);
 #pragma unroll
     for (int m = 0; m < R; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = acc_row(wave, m, r, kq);
-            if (row < a.B) {
-                const size_t o = (size_t)row * a.D + col;
+            if (row < rows) {
+                const size_t o = (size_t)(row0 + row) * a.D + col;
                 a.out[o] = a.base != nullptr ? fmaf(a.scale, acc[m][r], a.base[o]) : a.scale * acc[m][r];
             }
         }
 }
 
-struct RhBwdArgs {
-    const float* G; const float* K; const float* gamma;
-    const float* P; const float* H; const float* mean; const float* invstd;
-    float* dP; float* g_gamma; float* g_beta;
-    int B, D, act, training;
-    float scale;
-};
+// out = X K^T, nothing else: the product of the batches above 128 rows, whose BatchNorm statistics span several row
+// blocks (= workgroups) and are taken by rh_bn_fwd_kernel / rh_bn_bwd_kernel below
+template <int R>
+__global__ __launch_bounds__(kRhStripThreads) void rh_nt_strip_kernel(RhAxpyArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float rh_smem[];
+    float* As = rh_smem;
+    float* Ws = As + 2 * kRhWaves * R * 16 * RhSlab<R>::LDA;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, jj = lane & 15, kq = lane >> 4;
+    const int n0 = blockIdx.x * kRhCols, col = n0 + jj;
+    const int row0 = blockIdx.y * (kRhWaves * R * 16);
+    const int rows = a.B - row0 < kRhWaves * R * 16 ? a.B - row0 : kRhWaves * R * 16;
+    f32x4 acc[R];
+    strip_gemm<R, true>(a.X + (size_t)row0 * a.D, rows, a.D, a.D, a.K, a.D, n0, acc, As, Ws);
+#pragma unroll
+    for (int m = 0; m < R; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = acc_row(wave, m, r, kq);
+            if (row < rows) a.out[(size_t)(row0 + row) * a.D + col] = acc[m][r];
+        }
+}
+
+// ---- BatchNorm1d over a batch of any size, beside the products (64 features per workgroup; thread = (feature, row
+// quarter); the (B, 64) slice is read two or three times from L2) -------------------------------------------------
+constexpr int kBnCols = 64;
+__device__ __forceinline__ float bn_column_total(float v, float (*red)[kBnCols]) {
+    const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+    __syncthreads();
+    red[q][c] = v;
+    __syncthreads();
+    return (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
+// P (B, D) -> statistics, H = act(BN(P)); running statistics as in rh_fwd_strip_kernel
+__global__ __launch_bounds__(256) void rh_bn_fwd_kernel(RhFwdArgs a) {
+    __shared__ float red[4][kBnCols];
+    const int c = threadIdx.x & 63, q = threadIdx.x >> 6, col = blockIdx.x * kBnCols + c;
+    float mu, istd;
+    if (a.training) {
+        float s = 0.f;
+        for (int r = q; r < a.B; r += 4) s += a.P[(size_t)r * a.D + col];
+        mu = bn_column_total(s, red) / (float)a.B;
+        float v = 0.f;
+        for (int r = q; r < a.B; r += 4) { const float d = a.P[(size_t)r * a.D + col] - mu; v = fmaf(d, d, v); }
+        const float var = bn_column_total(v, red) / (float)a.B;
+        istd = 1.0f / sqrtf(var + a.eps);
+        if (q == 0 && a.run_mean != nullptr) {
+            const float unb = a.B > 1 ? var * (float)a.B / (float)(a.B - 1) : var;
+            a.run_mean[col] = (1.f - a.momentum) * a.run_mean[col] + a.momentum * mu;
+            a.run_var[col] = (1.f - a.momentum) * a.run_var[col] + a.momentum * unb;
+        }
+    } else {
+        mu = a.run_mean[col];
+        istd = 1.0f / sqrtf(a.run_var[col] + a.eps);
+    }
+    if (q == 0) { a.mean[col] = mu; a.invstd[col] = istd; }
+    const float g = a.gamma[col], bt = a.beta[col];
+    for (int r = q; r < a.B; r += 4) {
+        const size_t o = (size_t)r * a.D + col;
+        a.H[o] = act_fwd(fmaf((a.P[o] - mu) * istd, g, bt), a.act);
+    }
+}
+
+// dP holds G K^T on entry; on exit the gradient of P.  dgamma, dbeta.
+__global__ __launch_bounds__(256) void rh_bn_bwd_kernel(RhBwdArgs a) {
+    __shared__ float red[4][kBnCols];
+    const int c = threadIdx.x & 63, q = threadIdx.x >> 6, col = blockIdx.x * kBnCols + c;
+    const float mu = a.mean[col], istd = a.invstd[col], g = a.gamma[col];
+    float sb = 0.f, sg = 0.f;
+    for (int r = q; r < a.B; r += 4) {
+        const size_t o = (size_t)r * a.D + col;
+        const float dhn = a.scale * a.dP[o] * act_bwd(a.H[o], a.act);
+        sb += dhn;
+        sg = fmaf(dhn, (a.P[o] - mu) * istd, sg);
+    }
+    const float dbeta = bn_column_total(sb, red);
+    const float dgamma = bn_column_total(sg, red);
+    if (q == 0) { a.g_beta[col] = dbeta; a.g_gamma[col] = dgamma; }
+    const float inv_b = 1.0f / (float)a.B;
+    for (int r = q; r < a.B; r += 4) {
+        const size_t o = (size_t)r * a.D + col;
+        const float dhn = a.scale * a.dP[o] * act_bwd(a.H[o], a.act);
+        const float xhat = (a.P[o] - mu) * istd;
+        a.dP[o] = a.training ? g * istd * (dhn - (dbeta + xhat * dgamma) * inv_b) : g * istd * dhn;
+    }
+}
+
 
 // dH = scale * (G K^T); through the activation and the BatchNorm (training: batch statistics take part) -> dP, dgamma, dbeta
 template <int R>
@@ -376,26 +466,21 @@ __global__ __launch_bounds__(kRhThreads) void rh_outer_kernel(RhOuterArgs a) {
             }
 }
 
-template <int R> constexpr size_t strip_lds() {
+constexpr size_t strip_lds() {
     // X slabs + the larger of the two W-slab shapes, both double-buffered, + the reduction scratch
-    return (size_t)(2 * kRhWaves * R * 16 * RhSlab<R>::LDA + 2 * (kRhCols * RhSlab<R>::LDA > RhSlab<R>::BK * kRhLdN
-                    ? kRhCols * RhSlab<R>::LDA : RhSlab<R>::BK * kRhLdN) + kRhWaves * 64) * sizeof(float);
+    return (size_t)(2 * kRhWaves * 16 * RhSlab<1>::LDA + 2 * (kRhCols * RhSlab<1>::LDA > RhSlab<1>::BK * kRhLdN
+                    ? kRhCols * RhSlab<1>::LDA : RhSlab<1>::BK * kRhLdN) + kRhWaves * 64) * sizeof(float);
 }
-template <int R, typename ARGS, typename KERN>
-int launch_one(KERN kern, const ARGS& a, int D, hipStream_t st) {
+constexpr int kRhRows = kRhWaves * 16;                    // batch rows of one strip workgroup (128)
+template <typename ARGS, typename KERN>
+int launch_strip(KERN kern, const ARGS& a, int D, int row_blocks, hipStream_t st) {
     static unsigned long long configured = 0;             // one per kernel instantiation
-    if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)strip_lds<R>(), configured) != PDE_OK) return PDE_E_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(D / kRhCols), dim3(kRhStripThreads), strip_lds<R>(), st, a);
+    if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)strip_lds(), configured) != PDE_OK) return PDE_E_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(D / kRhCols, row_blocks), dim3(kRhStripThreads), strip_lds(), st, a);
     return check_launch();
 }
-template <typename ARGS, typename K1, typename K2, typename K4>
-int launch_strip(const ARGS& a, int B, int D, K1 k1, K2 k2, K4 k4, hipStream_t st) {
-    if (B <= 128) return launch_one<1>(k1, a, D, st);
-    if (B <= 256) return launch_one<2>(k2, a, D, st);
-    return launch_one<4>(k4, a, D, st);
-}
 
-bool rh_dims_ok(int B, int D) { return B >= 1 && B <= kRhMaxB && D >= 64 && (D % 64) == 0; }
+bool rh_dims_ok(int B, int D) { return B >= 1 && D >= 64 && (D % 64) == 0; }
 
 }  // namespace
 }  // namespace pde
@@ -416,10 +501,20 @@ int pde_sym_layer_forward(int32_t B, int32_t D, int32_t act, int32_t training, c
     if (!training && (!running_mean || !running_var)) return PDE_E_BADARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
     RhFwdArgs f{X, K, bn_weight, bn_bias, running_mean, running_var, P, H, mean, invstd, B, D, act, training ? 1 : 0, momentum, eps};
-    int rc = launch_strip(f, B, D, rh_fwd_strip_kernel<1>, rh_fwd_strip_kernel<2>, rh_fwd_strip_kernel<4>, st);
+    const int nblk = (B + kRhRows - 1) / kRhRows;
+    int rc;
+    if (nblk == 1) {                                      // the whole batch in one strip workgroup: statistics as epilogue
+        rc = launch_strip(rh_fwd_strip_kernel<1>, f, D, 1, st);
+    } else {                                              // product by row blocks, then the statistics over all of them
+        RhAxpyArgs p{X, K, nullptr, P, B, D, 1.0f};
+        rc = launch_strip(rh_nt_strip_kernel<1>, p, D, nblk, st);
+        if (rc != PDE_OK) return rc;
+        hipLaunchKernelGGL(rh_bn_fwd_kernel, dim3(D / kBnCols), dim3(256), 0, st, f);
+        rc = check_launch();
+    }
     if (rc != PDE_OK) return rc;
     RhAxpyArgs x{H, K, base, out, B, D, scale};
-    return launch_strip(x, B, D, rh_axpy_strip_kernel<1>, rh_axpy_strip_kernel<2>, rh_axpy_strip_kernel<4>, st);
+    return launch_strip(rh_axpy_strip_kernel<1>, x, D, nblk, st);
 }
 
 int pde_sym_layer_backward(int32_t B, int32_t D, int32_t act, int32_t training, const float* g_out, float scale,
@@ -432,10 +527,20 @@ int pde_sym_layer_backward(int32_t B, int32_t D, int32_t act, int32_t training, 
     if (act < kActIdentity || act > kActTanh) return PDE_E_BADARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
     RhBwdArgs b{g_out, K, bn_weight, P, H, mean, invstd, dP, g_bn_weight, g_bn_bias, B, D, act, training ? 1 : 0, scale};
-    int rc = launch_strip(b, B, D, rh_bwd_strip_kernel<1>, rh_bwd_strip_kernel<2>, rh_bwd_strip_kernel<4>, st);
+    const int nblk = (B + kRhRows - 1) / kRhRows;
+    int rc;
+    if (nblk == 1) {
+        rc = launch_strip(rh_bwd_strip_kernel<1>, b, D, 1, st);
+    } else {
+        RhAxpyArgs p{g_out, K, nullptr, dP, B, D, 1.0f};
+        rc = launch_strip(rh_nt_strip_kernel<1>, p, D, nblk, st);
+        if (rc != PDE_OK) return rc;
+        hipLaunchKernelGGL(rh_bn_bwd_kernel, dim3(D / kBnCols), dim3(256), 0, st, b);
+        rc = check_launch();
+    }
     if (rc != PDE_OK) return rc;
     RhAxpyArgs x{dP, K, nullptr, gX, B, D, 1.0f};
-    rc = launch_strip(x, B, D, rh_axpy_strip_kernel<1>, rh_axpy_strip_kernel<2>, rh_axpy_strip_kernel<4>, st);
+    rc = launch_strip(rh_axpy_strip_kernel<1>, x, D, nblk, st);
     if (rc != PDE_OK) return rc;
     RhOuterArgs o{dP, X, H, g_out, gK, B, D, scale};
     hipLaunchKernelGGL(rh_outer_kernel, dim3((D + 127) / 128, (D + 127) / 128), dim3(kRhThreads), 0, st, o);

@@ -905,7 +905,7 @@ class _SymLayerFn(torch.autograd.Function):
 
 
 def sym_layer_supported(X, bn) -> bool:
-    """Whether ``sym_layer`` takes this input: an fp32 CUDA batch of at most 512 rows whose feature count is a multiple of
+    """Whether ``sym_layer`` takes this input: an fp32 CUDA batch whose feature count is a multiple of
     64, outside autocast, and a BatchNorm1d with affine parameters and a fixed momentum."""
     if not (X.is_cuda and X.dtype == torch.float32 and X.dim() >= 2 and X.shape[0] > 0) or torch.is_autocast_enabled():
         return False

@@ -360,7 +360,8 @@ int pde_jacobi_backward(int32_t B, int32_t H, int32_t W, int32_t nt,
  * training != 0: batch statistics (biased variance for normalisation; running statistics updated with `momentum`
  * and the unbiased variance, as torch.nn.BatchNorm1d does; running_* may be NULL = not tracked); training == 0:
  * running statistics.  P, H, mean[D], invstd[D] are written for the backward; base may be NULL (then out = scale*(H K)).
- * F_sym(Y) itself is base = NULL, scale = -1.  B <= 512, D a multiple of 64 (pde_sym_layer_supported). */
+ * F_sym(Y) itself is base = NULL, scale = -1.  D a multiple of 64 (pde_sym_layer_supported); up to 128 batch rows the
+ * statistics are the epilogue of the first product, larger batches run it by row blocks with a statistics pass beside it. */
 int pde_sym_layer_supported(int32_t B, int32_t D);
 int pde_sym_layer_forward(int32_t B, int32_t D, int32_t act, int32_t training,
                           const float* X, const float* K, const float* bn_weight, const float* bn_bias,

@@ -85,7 +85,7 @@ def test_symmetric_layer_at_the_reference_size():
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,D,act,training", [(5, 64, "relu", True), (33, 128, "tanh", True), (130, 192, "relu", True),
                                               (300, 1024, "relu", True), (1, 64, "relu", False), (257, 320, "identity", False),
-                                              (512, 128, "relu", True)])
+                                              (512, 128, "relu", True), (700, 192, "tanh", True), (1030, 64, "relu", False)])
 def test_symmetric_layer_vs_oracle(B, D, act, training):
     """ragged and single-row batches, every row-block count of the strip kernels, the three activations, both modes
     (no 2-row training batch: BatchNorm over two samples maps every input to +-1, its input gradient is identically zero
@@ -129,8 +129,8 @@ def test_symmetric_layer_vs_oracle(B, D, act, training):
 def test_boundary_rejects_what_it_cannot_do():
     from cnn_with_pde_amd import _lib as L
     lib = L.load()
-    assert lib.pde_sym_layer_supported(512, 3072) == 1
-    assert lib.pde_sym_layer_supported(513, 3072) == 0 and lib.pde_sym_layer_supported(8, 96) == 0
+    assert lib.pde_sym_layer_supported(512, 3072) == 1 and lib.pde_sym_layer_supported(5000, 3072) == 1
+    assert lib.pde_sym_layer_supported(0, 3072) == 0 and lib.pde_sym_layer_supported(8, 96) == 0
     x = torch.zeros(8, 64, device="cuda")
     k = torch.zeros(64, 64, device="cuda")
     v = torch.zeros(64, device="cuda")
@@ -141,7 +141,7 @@ def test_boundary_rejects_what_it_cannot_do():
     assert ok(8, 64, 1, p(x)) == 0
     assert ok(8, 64, 1, None) == -1            # null pointer
     assert ok(8, 64, 7, p(x)) == -1            # unknown activation
-    assert ok(600, 64, 1, p(x)) == -1          # more batch rows than a strip workgroup holds
+    assert ok(8, 100, 1, p(x)) == -1           # feature count not a multiple of 64
     # eval mode needs running statistics
     assert lib.pde_sym_layer_forward(8, 64, 1, 0, p(x), p(k), p(v), p(v), None, None, 0.1, 1e-5, None, -1.0,
                                      p(x), p(x), p(v), p(v), p(x), st) == -1
