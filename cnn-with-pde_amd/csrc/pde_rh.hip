@@ -395,75 +395,82 @@ struct RhOuterArgs {
 };
 
 // out[i][j] = sum_b A1[b][i] B1[b][j] + s2 * sum_b A2[b][i] B2[b][j]: the gradient of K from both of its uses
-// (dP^T X from the first product, H^T dF from the second).  128 x 128 tile per workgroup, wave (wi, wj) a 64 x 64 quarter.
+// (dP^T X from the first product, H^T dF from the second).  64 x 192 tile per workgroup, wave (wi, wj) a 32 x 96 part
+// (three 32 x 32 accumulators): D = 3072 is 48 x 16 = 768 tiles, exactly three per CU — with 128 x 128 tiles (576) a
+// quarter of the CUs carried three workgroups and the others two, and the launch took as long as the former (77 us).
+constexpr int kOutTi = 64, kOutTj = 192;
 __global__ __launch_bounds__(kRhThreads) void rh_outer_kernel(RhOuterArgs a) {
-    constexpr int BKB = 8, LD = 128 + 4;
-    __shared__ __attribute__((aligned(16))) float Sa[BKB * LD];
-    __shared__ __attribute__((aligned(16))) float Sb[BKB * LD];
+    constexpr int BKB = 16, LDA_ = kOutTi + 4, LDB_ = kOutTj + 4;
+    __shared__ __attribute__((aligned(16))) float Sa[2][BKB * LDA_];      // double-buffered: one barrier per slab
+    __shared__ __attribute__((aligned(16))) float Sb[2][BKB * LDB_];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, jj = lane & 31, kh = lane >> 5;
-    const int i0 = blockIdx.y * 128, j0 = blockIdx.x * 128;
+    const int i0 = blockIdx.y * kOutTi, j0 = blockIdx.x * kOutTj;
     const int wi = wave >> 1, wj = wave & 1;
-    f32x16 acc[2][2];
+    f32x16 acc[3];
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
+    for (int q = 0; q < 3; ++q)
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[p][q][r] = 0.f;
-    const int Bp = (a.B + BKB - 1) / BKB * BKB;
-    const int row = tid >> 5, c4 = tid & 31;              // slab row (batch sample), float4 column
-    float4 pa, pb;
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    const int Bp = (a.B + BKB - 1) / BKB * BKB;         // (the two products are walked as 2 Bp virtual batch rows)
+    // a slab is BKB batch rows of [64 | 192] floats = 64 float4 per row: four float4 per thread
+    constexpr int PT = BKB * 64 / kRhThreads;
+    float4 pv[PT];
     auto fetch = [&](int v) __attribute__((always_inline)) {          // v: virtual batch row of the slab's first row
         const bool second = v >= Bp;
-        const int b = (second ? v - Bp : v) + row;
         const float* A = second ? a.A2 : a.A1;
         const float* Bm = second ? a.B2 : a.B1;
-        pa = pb = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (b < a.B) {                                    // (D is a multiple of 32: a float4 never straddles the edge)
-            if (i0 + 4 * c4 < a.D) pa = *reinterpret_cast<const float4*>(A + (size_t)b * a.D + i0 + 4 * c4);
-            if (j0 + 4 * c4 < a.D) pb = *reinterpret_cast<const float4*>(Bm + (size_t)b * a.D + j0 + 4 * c4);
-            if (second) { pb.x *= a.s2; pb.y *= a.s2; pb.z *= a.s2; pb.w *= a.s2; }
+#pragma unroll
+        for (int m = 0; m < PT; ++m) {
+            const int f = tid + kRhThreads * m, row = f >> 6, c4 = f & 63;
+            const int b = (second ? v - Bp : v) + row;
+            pv[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b < a.B) {                                // (D is a multiple of 64: a float4 never straddles the edge)
+                if (c4 < kOutTi / 4) {
+                    if (i0 + 4 * c4 < a.D) pv[m] = *reinterpret_cast<const float4*>(A + (size_t)b * a.D + i0 + 4 * c4);
+                } else if (j0 + 4 * (c4 - kOutTi / 4) < a.D) {
+                    pv[m] = *reinterpret_cast<const float4*>(Bm + (size_t)b * a.D + j0 + 4 * (c4 - kOutTi / 4));
+                    if (second) { pv[m].x *= a.s2; pv[m].y *= a.s2; pv[m].z *= a.s2; pv[m].w *= a.s2; }
+                }
+            }
         }
     };
-    auto stage = [&]() __attribute__((always_inline)) {
-        *reinterpret_cast<float4*>(Sa + row * LD + 4 * c4) = pa;
-        *reinterpret_cast<float4*>(Sb + row * LD + 4 * c4) = pb;
+    auto stage = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < PT; ++m) {
+            const int f = tid + kRhThreads * m, row = f >> 6, c4 = f & 63;
+            if (c4 < kOutTi / 4) *reinterpret_cast<float4*>(Sa[buf] + row * LDA_ + 4 * c4) = pv[m];
+            else *reinterpret_cast<float4*>(Sb[buf] + row * LDB_ + 4 * (c4 - kOutTi / 4)) = pv[m];
+        }
     };
     const int total = 2 * Bp;
     fetch(0);
-    stage();
+    stage(0);
     __syncthreads();
+    int buf = 0;
     for (int v = 0; v < total; v += BKB) {
         const bool more = v + BKB < total;
         if (more) fetch(v + BKB);
 #pragma unroll
         for (int s = 0; s < BKB / 2; ++s) {
-            float af[2], bf[2];
+            const float af = Sa[buf][(2 * s + kh) * LDA_ + wi * 32 + jj];
+            float bf[3];
 #pragma unroll
-            for (int p = 0; p < 2; ++p) af[p] = Sa[(2 * s + kh) * LD + wi * 64 + p * 32 + jj];
+            for (int q = 0; q < 3; ++q) bf[q] = Sb[buf][(2 * s + kh) * LDB_ + wj * 96 + q * 32 + jj];
 #pragma unroll
-            for (int q = 0; q < 2; ++q) bf[q] = Sb[(2 * s + kh) * LD + wj * 64 + q * 32 + jj];
-#pragma unroll
-            for (int p = 0; p < 2; ++p)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[p], bf[q], acc[p][q], 0, 0, 0);
+            for (int q = 0; q < 3; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf[q], acc[q], 0, 0, 0);
         }
+        if (more) stage(buf ^ 1);                         // the other buffer: last read one barrier ago
         __syncthreads();
-        if (more) {
-            stage();
-            __syncthreads();
-        }
+        buf ^= 1;
     }
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
+    for (int q = 0; q < 3; ++q)
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = i0 + wi * 64 + p * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                const int j = j0 + wj * 64 + q * 32 + jj;
-                if (i < a.D && j < a.D) a.out[(size_t)i * a.D + j] = acc[p][q][r];
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int i = i0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            const int j = j0 + wj * 96 + q * 32 + jj;
+            if (i < a.D && j < a.D) a.out[(size_t)i * a.D + j] = acc[q][r];
+        }
 }
 
 constexpr size_t strip_lds() {
@@ -543,7 +550,7 @@ int pde_sym_layer_backward(int32_t B, int32_t D, int32_t act, int32_t training, 
     rc = launch_strip(rh_axpy_strip_kernel<1>, x, D, nblk, st);
     if (rc != PDE_OK) return rc;
     RhOuterArgs o{dP, X, H, g_out, gK, B, D, scale};
-    hipLaunchKernelGGL(rh_outer_kernel, dim3((D + 127) / 128, (D + 127) / 128), dim3(kRhThreads), 0, st, o);
+    hipLaunchKernelGGL(rh_outer_kernel, dim3((D + kOutTj - 1) / kOutTj, (D + kOutTi - 1) / kOutTi), dim3(kRhThreads), 0, st, o);
     return check_launch();
 }
 
