@@ -17,7 +17,8 @@ PDE_AXIS_X, PDE_AXIS_Y = 0, 1
 
 ERRORS = {
     -1: "PDE_E_BADARG (null pointer, bad dimension or enum)",
-    -2: "PDE_E_UNSUPPORTED_N (line length must be a multiple of 4 in [8, 32])",
+    -2: "PDE_E_UNSUPPORTED_N (line length outside [2, 128], or a per-step / one-launch entry point at a line length "
+        "without fused kernels: those exist for multiples of 4 in [8, 32])",
     -3: "PDE_E_TOO_MANY_SWEEPS",
     -4: "PDE_E_LAUNCH (HIP launch failed)",
     -5: "PDE_E_WORKSPACE (workspace too small or misaligned)",
@@ -57,6 +58,7 @@ _D = C.POINTER(PdeAdiDesc)
 
 # name -> (restype, argtypes): must list every symbol include/pdecnn.h declares
 SIGNATURES = {
+    "pde_adi_line_length_path": (C.c_int, [_i32]),
     "pde_adi_forward_workspace_bytes": (_sz, [_D]),
     "pde_adi_backward_workspace_bytes": (_sz, [_D, _i32]),
     "pde_adi_forward": (C.c_int, [_D, _vp, _vp, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _vp, _sz, _vp]),

@@ -42,6 +42,7 @@
 #include "pde_adi_small.h"
 #include "pde_adi_wide.h"
 #include "pde_adi_launch.h"
+#include "pde_adi_gen.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -497,10 +498,13 @@ __global__ __launch_bounds__(1024) void adi_pgrad_kernel(PgradArgs a) {
 // ------------------------------------------------------------------------------------
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-int check_desc(const PdeAdiDesc* d) {
+// fused: the line length has register-resident sweep kernels (pde_adi_dev.h); otherwise pde_adi_gen.hip serves the
+// whole-schedule entry points (forward, backward, kappa_max) and the per-step / one-launch families refuse
+bool fused_n(int N) { return N >= 8 && N <= PDE_MAX_N && (N % 4) == 0; }
+int check_desc(const PdeAdiDesc* d, bool allow_generic = false) {
     if (!d) return PDE_E_BADARG;
     if (d->B <= 0 || d->C <= 0 || d->num_sweeps <= 0) return PDE_E_BADARG;
-    if (d->N < 8 || d->N > PDE_MAX_N || (d->N % 4) != 0) return PDE_E_UNSUPPORTED_N;
+    if (!fused_n(d->N) && !(allow_generic && gen_n_ok(d->N))) return PDE_E_UNSUPPORTED_N;
     if (d->num_sweeps > PDE_MAX_SWEEPS) return PDE_E_TOO_MANY_SWEEPS;
     if (d->io_dtype != PDE_IO_F32 && d->io_dtype != PDE_IO_BF16) return PDE_E_BADARG;
     for (int s = 0; s < d->num_sweeps; ++s)
@@ -826,13 +830,17 @@ using namespace pde;
 
 extern "C" {
 
+int pde_adi_line_length_path(int32_t N) { return fused_n(N) ? 1 : (gen_n_ok(N) ? 2 : 0); }
+
 size_t pde_adi_forward_workspace_bytes(const PdeAdiDesc* d) {
-    if (check_desc(d) != PDE_OK) return 0;
+    if (check_desc(d, true) != PDE_OK) return 0;
+    if (!fused_n(d->N)) return gen_forward_workspace_bytes(d);
     return coef_bytes(d) + tab_bytes() + flag_bytes(d);
 }
 
 size_t pde_adi_backward_workspace_bytes(const PdeAdiDesc* d, int32_t num_checkpoints) {
-    if (check_desc(d) != PDE_OK || num_checkpoints < 0) return 0;
+    if (check_desc(d, true) != PDE_OK || num_checkpoints < 0) return 0;
+    if (!fused_n(d->N)) return gen_backward_workspace_bytes(d, num_checkpoints);
     const int G = groups_per_channel(d, kWaves * kJBwd, 8 / kWaves);
     size_t b = coef_bytes(d) + tab_bytes() + flag_bytes(d);
     b += align_up((size_t)G * d->C * 4 * kImage * sizeof(float), 256) + 2048;    // + diagnostics scratch
@@ -843,11 +851,19 @@ size_t pde_adi_backward_workspace_bytes(const PdeAdiDesc* d, int32_t num_checkpo
 int pde_adi_forward(const PdeAdiDesc* d, const void* u, void* y, const float* alpha_base, const float* beta_base,
                     const float* alpha_slope, const float* beta_slope, float* kappa_max, float* kappa_max_host,
                     void* kappa_event, void* workspace, size_t workspace_bytes, void* stream) {
-    int rc = check_desc(d);
+    int rc = check_desc(d, true);
     if (rc != PDE_OK) return rc;
     if (!u || !y || !alpha_base || !beta_base || !alpha_slope || !beta_slope || !workspace) return PDE_E_BADARG;
     if (workspace_bytes < pde_adi_forward_workspace_bytes(d) || ((uintptr_t)workspace & 15)) return PDE_E_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!fused_n(d->N)) {                                 // any other line length: one thread per line (pde_adi_gen.hip)
+        if (kappa_max_host && !kappa_max) return PDE_E_BADARG;
+        rc = gen_factor(d, alpha_base, beta_base, alpha_slope, beta_slope, kappa_max, workspace, st);
+        if (rc != PDE_OK) return rc;
+        rc = publish_kmax(kappa_max, kappa_max_host, kappa_event, d->num_sweeps, st);
+        if (rc != PDE_OK) return rc;
+        return gen_forward_sweeps(d, u, y, workspace, st);
+    }
     float* coef = static_cast<float*>(workspace);
     SweepTab* tab = reinterpret_cast<SweepTab*>(static_cast<char*>(workspace) + coef_bytes(d));
     int* varying = reinterpret_cast<int*>(static_cast<char*>(workspace) + coef_bytes(d) + tab_bytes());
@@ -864,7 +880,7 @@ int pde_adi_backward(const PdeAdiDesc* d, const void* gy, const void* y, const v
                      const float* beta_slope, float* g_alpha_base, float* g_beta_base, float* g_alpha_slope,
                      float* g_beta_slope, const void* fwd_workspace, void* workspace, size_t workspace_bytes,
                      void* stream) {
-    int rc = check_desc(d);
+    int rc = check_desc(d, true);
     if (rc != PDE_OK) return rc;
     if (!gy || !y || !gu || !alpha_base || !beta_base || !alpha_slope || !beta_slope || !g_alpha_base ||
         !g_beta_base || !g_alpha_slope || !g_beta_slope || !workspace)
@@ -874,6 +890,9 @@ int pde_adi_backward(const PdeAdiDesc* d, const void* gy, const void* y, const v
     if (rc != PDE_OK) return rc;
     if (workspace_bytes < pde_adi_backward_workspace_bytes(d, nck) || ((uintptr_t)workspace & 15)) return PDE_E_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!fused_n(d->N))
+        return gen_backward(d, gy, y, u, ckpt_mask, nck, Sf, gu, alpha_base, beta_base, alpha_slope, beta_slope, g_alpha_base,
+                            g_beta_base, g_alpha_slope, g_beta_slope, fwd_workspace, workspace, st);
     const int G = groups_per_channel(d, kWaves * kJBwd, 8 / kWaves);
     char* ws = static_cast<char*>(workspace);
     float* coef = reinterpret_cast<float*>(ws);           ws += coef_bytes(d);
@@ -1340,10 +1359,11 @@ int pde_adi_small_backward(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t
 
 int pde_adi_kappa_max(const PdeAdiDesc* d, const float* alpha_base, const float* beta_base, const float* alpha_slope,
                       const float* beta_slope, float* kappa_max, void* stream) {
-    int rc = check_desc(d);
+    int rc = check_desc(d, true);
     if (rc != PDE_OK) return rc;
     if (!alpha_base || !beta_base || !alpha_slope || !beta_slope || !kappa_max) return PDE_E_BADARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!fused_n(d->N)) return gen_kappa_max(d, alpha_base, beta_base, alpha_slope, beta_slope, kappa_max, st);
     if (hipMemsetAsync(kappa_max, 0, (size_t)d->num_sweeps * sizeof(float), st) != hipSuccess) return PDE_E_LAUNCH;
     FactorArgs fa;
     fill_factor_args(fa, d, alpha_base, beta_base, alpha_slope, beta_slope);

@@ -965,7 +965,10 @@ __device__ __forceinline__ void adi_bwd_body(const SweepArgs& a, int blk) {
         if (more && s == (axs == PDE_AXIS_Y ? first_y : first_x)) dts -= (axs == PDE_AXIS_Y ? tlast_y : tlast_x);
         const float* crow = rec + l * kLineStride + hf * kHalfPad;
         // the newest sweep of my chunk has no twin before it (the previous item belongs to another chunk)
-        const bool twin = decltype(TWINC)::value && a.pair_x != 0 && s != a.S - 1;
+#ifndef PDE_BWD_NO_TWIN
+#define PDE_BWD_NO_TWIN 0   // 1: every sweep reads its own coefficient rows (no rows kept across the twin x sweeps)
+#endif
+        const bool twin = !PDE_BWD_NO_TWIN && decltype(TWINC)::value && a.pair_x != 0 && s != a.S - 1;
         const bool abl_skip = (PDE_ABL & 1) && abl_loaded;
         abl_loaded = true;
         if (!twin && !abl_skip) cjn = rec[kB_Jn + l];

@@ -713,6 +713,18 @@ def adi_diffuse_mixed(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coef
     steps = tuple(tuple(st) for st in steps)
     if len({len(st) for st in steps}) != 1:
         raise ValueError("every step must have the same number of sweeps")
+    if u.dim() == 4 and u.is_cuda and L.load().pde_adi_line_length_path(int(u.shape[-1])) == 2:
+        # a line length without fused kernels (pde_adi_line_length_path: any size up to PDE_MAX_N_GENERIC): the per-step
+        # entry points do not exist there; compose the layer from its own pieces — the channel operator and the sweeps of
+        # one step per call, chained by autograd (the step-local checkpoint mask applies to every step unchanged)
+        for st in steps:
+            if mode == "pre":
+                u = channel_mix(u, M)
+            u = adi_diffuse(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff, st, smooth3=smooth3,
+                            clamp_max=clamp_max, eps=eps, checkpoints=checkpoints)
+            if mode == "post":
+                u = channel_mix(u, M)
+        return u
     return _AdiMixedFn.apply(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff, M, steps, mode, bool(smooth3),
                              clamp_max, float(eps), checkpoints, kmax_sink)
 

@@ -25,11 +25,13 @@ extern "C" {
 #endif
 
 #define PDE_MAX_SWEEPS 96          /* e.g. 32 Strang steps */
-#define PDE_MAX_N 32               /* line length of the implicit layers (28, 32 in the reference) */
+#define PDE_MAX_N 32               /* longest line of the fused implicit kernels (N = 8, 12, ..., 32; the reference uses 28, 32) */
+#define PDE_MAX_N_GENERIC 128      /* longest line of the any-size path (one thread per line, plane in LDS)              */
 
 #define PDE_OK 0
 #define PDE_E_BADARG (-1)          /* null pointer, non-positive dim, bad enum */
-#define PDE_E_UNSUPPORTED_N (-2)   /* N not a multiple of 4 or > PDE_MAX_N */
+#define PDE_E_UNSUPPORTED_N (-2)   /* whole-schedule calls: N < 2 or > PDE_MAX_N_GENERIC; per-step / one-launch
+                                      families: N not one of the fused line lengths */
 #define PDE_E_TOO_MANY_SWEEPS (-3)
 #define PDE_E_LAUNCH (-4)          /* hipLaunch failed; hipPeekAtLastError/hipGetLastError has details */
 #define PDE_E_WORKSPACE (-5)       /* workspace too small / misaligned */
@@ -64,6 +66,14 @@ typedef struct PdeAdiDesc {
 } PdeAdiDesc;
 
 /* ---- K1: implicit ADI time-stepper -------------------- */
+
+/* Which kernels serve line length N: 1 = fused register-resident sweeps (N = 8, 12, ..., 32: every entry point of
+ * this header), 2 = the any-size path (2 <= N <= PDE_MAX_N_GENERIC, any other N: the reference's classes take any `size`,
+ * mnist_test.py:12, cifar10.py:25, SVHN.py:13) — pde_adi_forward / pde_adi_backward / pde_adi_kappa_max and their
+ * workspace queries only, one thread per line with the reference's own Thomas recurrences (mnist_test.py:151-198); a
+ * layer with a channel operator is then composed per step by the caller (pde_channel_mix_* + one-step schedules),
+ * 0 = unsupported. */
+int pde_adi_line_length_path(int32_t N);
 
 /* Bytes of scratch the forward/backward calls need (256-byte aligned base expected). */
 size_t pde_adi_forward_workspace_bytes(const PdeAdiDesc* d);

@@ -46,9 +46,15 @@ def test_argument_validation_without_gpu():
     from cnn_with_pde_amd import _lib
     lib = _lib.load()
     d = _lib.PdeAdiDesc()
-    d.B, d.C, d.N, d.num_sweeps = 1, 1, 30, 3          # 30 is not a supported line length
+    d.B, d.C, d.N, d.num_sweeps = 1, 1, 130, 3         # longer than any path holds (PDE_MAX_N_GENERIC = 128)
     assert lib.pde_adi_forward_workspace_bytes(C.byref(d)) == 0
     assert lib.pde_adi_forward(C.byref(d), None, None, None, None, None, None, None, None, None, None, 0, None) == -2
+    d.N = 30                                           # no fused kernels: served by the any-size path ...
+    assert lib.pde_adi_line_length_path(30) == 2 and lib.pde_adi_line_length_path(32) == 1 and lib.pde_adi_line_length_path(1) == 0
+    assert lib.pde_adi_forward_workspace_bytes(C.byref(d)) > 0
+    assert lib.pde_adi_forward(C.byref(d), None, None, None, None, None, None, None, None, None, None, 0, None) == -1
+    assert lib.pde_adi_steps_workspace_bytes(C.byref(d), 3) == 0      # ... which has no per-step / one-launch entry points
+    assert lib.pde_adi_small_supported(C.byref(d), 3) == 0
     d.N, d.num_sweeps = 32, _lib.PDE_MAX_SWEEPS + 1
     assert lib.pde_adi_forward(C.byref(d), None, None, None, None, None, None, None, None, None, None, 0, None) == -3
     d.num_sweeps = 3

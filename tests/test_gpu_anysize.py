@@ -1,0 +1,169 @@
+"""Line lengths WITHOUT fused kernels (anything but 8, 12, ..., 32, up to 128): the reference's classes take any `size`
+(mnist_test.py:12, cifar10.py:25, SVHN.py:13, cifar_2version.py:25), and the library serves those through
+csrc/pde_adi_gen.hip — one thread per line, the reference's own Thomas recurrences — behind the same C entry points
+(pde_adi_forward / pde_adi_backward / pde_adi_kappa_max).  Every layer class against the oracle at 1e-5 (max-norm relative),
+with checkpoints, bf16 tensors, the coefficient maxima, repeatability."""
+import os
+import random
+
+import pytest
+import torch
+
+import golden_util as G
+from oracle import pde_oracle as O
+from test_gpu_parity import TOL, _compare, _perturb, quiet
+
+pytestmark = pytest.mark.gpu
+
+
+def test_path_query():
+    import cnn_with_pde_amd._lib as L
+    lib = L.load()
+    assert [lib.pde_adi_line_length_path(n) for n in (1, 2, 6, 8, 28, 30, 32, 36, 64, 128, 129)] == \
+        [0, 2, 2, 1, 1, 2, 1, 2, 2, 2, 0]
+
+
+@pytest.mark.parametrize("N", [6, 30, 36, 40, 50, 64])
+def test_every_layer_class_vs_oracle(N):
+    import cnn_with_pde_amd as P
+    g = torch.Generator().manual_seed(900 + N)
+    # mnist: one channel, smoothed coefficients, Strang
+    ly = quiet(P.MnistDiffusionLayer, N, 0.01, 1.0, 1.3, 3)
+    _perturb(ly, g, 0.2, 0.4)
+    u, gy = torch.randn(5, 1, N, N, generator=g), torch.randn(5, 1, N, N, generator=g)
+    _compare(ly, lambda a, p: O.adi_forward(a, p, O.mnist_spec(N, 0.01, 1.0, 1.3, 3)), u, gy)
+    # cifar10: clamp to [eps, 10], channel mixing before every step (composed per step at these sizes)
+    ly = quiet(P.EnhancedDiffusionLayer, N, 3, dt=0.02, num_steps=3)
+    _perturb(ly, g, 0.2, 0.5)
+    with torch.no_grad():
+        ly.channel_mixing.copy_(torch.eye(3) + 0.1 * torch.randn(3, 3, generator=g))
+    u, gy = torch.randn(7, 3, N, N, generator=g), torch.randn(7, 3, N, N, generator=g)
+    _compare(ly, lambda a, p: O.adi_forward(a, p, O.cifar10_spec(N, 3, dt=0.02, num_steps=3)), u, gy)
+    # cifar_2version: Lie split
+    ly = quiet(P.LearnableDiffusionLayer, N, 2, 0.03, 1.0, 1.2, 3)
+    _perturb(ly, g, 0.2, 0.4)
+    u, gy = torch.randn(4, 2, N, N, generator=g), torch.randn(4, 2, N, N, generator=g)
+    _compare(ly, lambda a, p: O.adi_forward(a, p, O.cifar2_spec(N, 2, 0.03, 1.0, 1.2, 3)), u, gy)
+    # SVHN: smoothed, coupling after every step, skip blend
+    ly = P.SvhnDiffusionLayer(N, 4, 0.05, 1.0, 2)
+    _perturb(ly, g, 0.2, 0.3)
+    with torch.no_grad():
+        ly.channel_coupling.copy_(torch.eye(4) + 0.05 * torch.randn(4, 4, generator=g))
+        ly.skip_weight.fill_(0.2)
+    u, gy = torch.randn(3, 4, N, N, generator=g), torch.randn(3, 4, N, N, generator=g)
+    _compare(ly, lambda a, p: O.adi_forward(a, p, O.svhn_spec(N, 4, 0.05, 1.0, 2)), u, gy)
+
+
+@pytest.mark.parametrize("N", [100, 128])
+def test_longest_lines(N):
+    """Two threads' worth of waves per plane, more than 64 KB of LDS per workgroup."""
+    import cnn_with_pde_amd as P
+    g = torch.Generator().manual_seed(77 + N)
+    ly = quiet(P.EnhancedDiffusionLayer, N, 2, dt=0.02, num_steps=2, channel_mixing_enabled=False)
+    _perturb(ly, g, 0.2, 0.5)
+    with torch.no_grad():
+        ly.channel_mixing.copy_(torch.eye(2))
+    u, gy = torch.randn(3, 2, N, N, generator=g), torch.randn(3, 2, N, N, generator=g)
+    _compare(ly, lambda a, p: O.adi_forward(a, p, O.cifar10_spec(N, 2, dt=0.02, num_steps=2)), u, gy)
+
+
+def test_clamp_masks_that_move_in_time():
+    """Coefficients that cross both clamp bounds during the schedule: the pass-through mask is per sweep."""
+    import cnn_with_pde_amd as P
+    N = 36
+    g = torch.Generator().manual_seed(5)
+    ly = quiet(P.EnhancedDiffusionLayer, N, 2, dt=0.5, num_steps=3, channel_mixing_enabled=False)
+    with torch.no_grad():
+        ly.channel_mixing.copy_(torch.eye(2))
+        ly.alpha_base.copy_(9.0 + 2.0 * torch.rand(2, N, N, generator=g))          # around clamp_max = 10
+        ly.alpha_time_coeff.copy_(2.0 * torch.randn(2, N, N, generator=g))
+        ly.beta_base.copy_(0.3 * torch.randn(2, N, N, generator=g))                 # around the floor
+        ly.beta_time_coeff.copy_(torch.randn(2, N, N, generator=g))
+    u, gy = torch.randn(6, 2, N, N, generator=g), torch.randn(6, 2, N, N, generator=g)
+    _compare(ly, lambda a, p: O.adi_forward(a, p, O.cifar10_spec(N, 2, dt=0.5, num_steps=3)), u, gy, tol=2e-5)
+
+
+def test_checkpoint_modes_agree_and_match_oracle():
+    """Large coefficients: rebuilding the state backwards amplifies rounding, the checkpoint plan must hold 1e-5."""
+    import cnn_with_pde_amd as P
+    N = 40
+    g = torch.Generator().manual_seed(6)
+    spec = O.mnist_spec(N, 0.3, 1.0, 1.0, 4)
+    u, gy = torch.randn(4, 1, N, N, generator=g), torch.randn(4, 1, N, N, generator=g)
+    outs = {}
+    for ck in ("auto", (1 << 11) - 1, 0b010010010010):
+        ly = quiet(P.MnistDiffusionLayer, N, 0.3, 1.0, 1.0, 4)
+        torch.manual_seed(1)
+        _perturb(ly, torch.Generator().manual_seed(8), 0.2, 0.3)
+        ly.checkpoint_policy = ck
+        errs = _compare(ly, lambda a, p: O.adi_forward(a, p, spec), u, gy, tol=TOL if ck == "auto" or ck == (1 << 11) - 1 else 1e-3)
+        outs[ck] = errs
+    assert outs["auto"]["y"] == outs[(1 << 11) - 1]["y"]
+
+
+def test_bf16_tensors():
+    import cnn_with_pde_amd as P
+    N = 48
+    g = torch.Generator().manual_seed(21)
+    ly = quiet(P.EnhancedDiffusionLayer, N, 3, dt=0.02, num_steps=2, channel_mixing_enabled=False)
+    _perturb(ly, g, 0.1, 0.2)
+    with torch.no_grad():
+        ly.channel_mixing.copy_(torch.eye(3))
+    u = torch.randn(5, 3, N, N, generator=g).bfloat16().float()
+    gy = torch.randn(5, 3, N, N, generator=g).bfloat16().float()
+    _compare(ly, lambda a, p: O.adi_forward(a, p, O.cifar10_spec(N, 3, dt=0.02, num_steps=2)), u, gy, tol=2e-2,
+             dtype=torch.bfloat16)
+
+
+def test_kappa_max_and_repeatability():
+    import cnn_with_pde_amd as P
+    from cnn_with_pde_amd import functional as F_
+    N = 44
+    g = torch.Generator().manual_seed(31)
+    ly = quiet(P.MnistDiffusionLayer, N, 0.05, 1.0, 1.5, 3)
+    _perturb(ly, g, 0.3, 0.5)
+    ly = ly.cuda()
+    sweeps = ly._schedule().flat
+    km = F_.kappa_max_async(torch.empty(1, 1, N, N, device="cuda"), ly.alpha_base, ly.beta_base, ly.alpha_time_coeff,
+                            ly.beta_time_coeff, sweeps, smooth3=True, clamp_max=None, eps=ly.stability_eps)
+    km.event.synchronize()
+    spec = O.mnist_spec(N, 0.05, 1.0, 1.5, 3)
+    want = []
+    for axis, delta, t in O.sweep_schedule(spec):
+        base, slope, h = ((ly.alpha_base, ly.alpha_time_coeff, spec.dx) if axis == 0 else (ly.beta_base, ly.beta_time_coeff, spec.dy))
+        th = O.coefficient_at(base.detach().cpu(), slope.detach().cpu(), t, spec)
+        th = O._smooth3(th if axis == 0 else th.t().contiguous())
+        want.append(float((th * delta / h ** 2).max()))
+    got = km.host.tolist()[:len(want)]
+    assert max(abs(a - b) / b for a, b in zip(got, want)) < 1e-6, (got, want)
+    u = torch.randn(9, 1, N, N, generator=g).cuda()
+    gy = torch.randn(9, 1, N, N, generator=g).cuda()
+    res = []
+    for _ in range(2):
+        for p in ly.parameters():
+            p.grad = None
+        x = u.clone().requires_grad_(True)
+        y = ly(x)
+        y.backward(gy)
+        res.append([y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in ly.parameters()])
+        torch.empty(1 << 22, device="cuda").normal_()
+    assert all(torch.equal(a, b) for a, b in zip(*res))
+
+
+def _walk():
+    import test_gpu_fuzz as Z
+    rng = random.Random(4711 + int(os.environ.get("PDE_FUZZ_SEED", "0")))
+    out = []
+    for _ in range(max(12, int(os.environ.get("PDE_FUZZ_CASES", "0")) // 3)):
+        kind, _, C, steps, dt, dx, scale, slope, B = Z._draw(rng)
+        N = rng.choice([5, 6, 10, 18, 30, 33, 36, 40, 44, 50, 64])
+        out.append((kind, N, min(C, 8), steps, dt, dx, scale, slope, min(B, 7)))
+    return out
+
+
+@pytest.mark.parametrize("case", _walk(), ids=lambda c: "-".join(str(x) for x in c))
+def test_random_walk_over_other_line_lengths(case):
+    """The seeded random walk of tests/test_gpu_fuzz.py (layer kind, channels, steps, step size, coefficient scale, time slopes
+    that move the clamp masks, batch) at line lengths without fused kernels, odd ones included."""
+    import test_gpu_fuzz as Z
+    Z.check_case(case)

@@ -70,6 +70,11 @@ def _cases():
 
 @pytest.mark.parametrize("case", _cases(), ids=lambda c: "-".join(str(x) for x in c))
 def test_random_case_vs_oracle(case):
+    check_case(case)
+
+
+def check_case(case):
+    """One drawn layer call against the oracle (also used by tests/test_gpu_anysize.py for the other line lengths)."""
     kind, N, C, steps, dt, dx, scale, slope, B = case
     g = torch.Generator().manual_seed(zlib.crc32(repr(case).encode()))
     layer, spec = _build(kind, N, C, steps, dt, dx)
