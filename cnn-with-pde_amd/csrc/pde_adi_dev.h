@@ -1092,7 +1092,7 @@ __device__ __forceinline__ void adi_bwd_body(const SweepArgs& a, int blk) {
         if (PDE_BWD_ITEMB) dma_one(); else dma_next();
         dma_wait_all();
         __syncthreads();
-        // The two halves run the same loop with their own compile-time pattern (position of an item
+            // The two halves run the same loop with their own compile-time pattern (position of an item
         // inside its time step -> axis, chunk boundaries): x y x | x y x for the lower waves, the same
         // sequence cut one item earlier for the upper ones.
         auto run = [&](auto LAGC) __attribute__((always_inline)) {
@@ -1100,7 +1100,7 @@ __device__ __forceinline__ void adi_bwd_body(const SweepArgs& a, int blk) {
             int item = -LAG, s = a.S - 1, slot = 0;       // my next item, its sweep, its ring slot
 #pragma unroll 1
             for (int t = 0; t < nint; ++t) {
-                if (!resident && !PDE_BWD_ITEMB && !((PDE_ABL & 8) && t > 1)) dma_next();
+                if (!resident && !PDE_BWD_ITEMB && !((PDE_ABL & (8 | 64)) && t > 1)) dma_next();
                 sfor<0, SPS>([&](auto IC) __attribute__((always_inline)) {
                     constexpr int pos = (decltype(IC)::value - LAG + SPS) % SPS;     // 0: newest sweep of a step
                     constexpr int AX = ((SPS - 1 - pos) == 1) ? PDE_AXIS_Y : PDE_AXIS_X;
@@ -1143,6 +1143,7 @@ __device__ __forceinline__ void adi_bwd_body(const SweepArgs& a, int blk) {
 #ifdef PDE_STAMP
                 if (tl_on) tl[1] = stamp();
 #endif
+                if (!((PDE_ABL & 32) && t > 1))           // (ablation 32: DMA kept, barrier dropped; 64: the reverse)
                 __syncthreads();                          // ... everyone's have, and everyone is done reading
 #ifdef PDE_STAMP
                 if (tl_on) tl[2] = stamp();
