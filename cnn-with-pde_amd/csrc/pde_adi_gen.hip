@@ -113,62 +113,99 @@ __device__ __forceinline__ int gen_ck_slot(const unsigned long long (&ck)[2], in
     return __popcll(below) + ((s >> 6) ? __popcll(ck[0]) : 0);
 }
 
+// The per-line recurrences are serial, so what a thread waits for is latency: the loops below work in batches of kGenBatch
+// elements — all LDS reads of the plane and all coefficient reads (global memory, L2-resident) of a batch are issued
+// together, then the dependent arithmetic runs on registers, then the batch is written back.  (Written one element at a
+// time the compiler must keep every LDS read behind the previous element's LDS write — it cannot know the stride is not
+// zero — and a thread pays a full LDS or L2 round trip per element.)
+constexpr int kGenBatch = 8;
+
 // forward: one workgroup per plane; sweeps 0..S-1 on the plane in LDS ([row][N+1])
 template <typename IO>
 __global__ void gen_fwd_kernel(GenSweepArgs a) {
     extern __shared__ float X[];
-    const int N = a.N, ld = N + 1, tid = threadIdx.x, T = blockDim.x;
-    const size_t plane = (size_t)N * N, pb = (size_t)blockIdx.x * plane;      // blockIdx = b*C + c
+    const int N = a.N, ld = N + 1, tid = threadIdx.x, T = blockDim.x, NN = N * N;
+    const size_t plane = (size_t)NN, pb = (size_t)blockIdx.x * plane;         // blockIdx = b*C + c
     const int c = blockIdx.x % a.C;
-    for (int e = tid; e < N * N; e += T) X[(e / N) * ld + (e % N)] = GenIo<IO>::ld(a.in0, pb + e);
+    for (int e = tid; e < NN; e += T) X[(e / N) * ld + (e % N)] = GenIo<IO>::ld(a.in0, pb + e);
     __syncthreads();
     for (int s = 0; s < a.S; ++s) {
         const GenSweep sw = a.tab[s];
         if (tid < N) {
-            const float* f = a.fac + ((size_t)s * a.C + c) * kGenArr * plane;
+            const float* __restrict__ f = a.fac + ((size_t)s * a.C + c) * kGenArr * plane + tid;   // [arr][k][line = tid]
             float* v = X + (sw.axis == PDE_AXIS_X ? tid * ld : tid);
             const int st = (sw.axis == PDE_AXIS_X) ? 1 : ld;
             // d*_0 = d_0/den_0, d*_i = (d_i - a_i d*_{i-1})/den_i with a_i = -coeff_i   (mnist_test.py:167-185)
-            float prev = v[0] * f[2 * plane + tid];
+            float prev = v[0] * f[2 * plane];
             v[0] = prev;
-            for (int k = 1; k < N; ++k) {
-                const size_t o = (size_t)k * N + tid;
-                prev = (v[k * st] + f[o] * prev) * f[2 * plane + o];
-                v[k * st] = prev;
+            for (int k0 = 1; k0 < N; k0 += kGenBatch) {
+                float t[kGenBatch], co[kGenBatch], iv[kGenBatch];
+#pragma unroll
+                for (int j = 0; j < kGenBatch; ++j) {
+                    const int k = k0 + j < N ? k0 + j : N - 1;
+                    t[j] = v[k * st];
+                    co[j] = f[(size_t)k * N];
+                    iv[j] = f[2 * plane + (size_t)k * N];
+                }
+#pragma unroll
+                for (int j = 0; j < kGenBatch; ++j)
+                    if (k0 + j < N) { prev = (t[j] + co[j] * prev) * iv[j]; t[j] = prev; }
+#pragma unroll
+                for (int j = 0; j < kGenBatch; ++j)
+                    if (k0 + j < N) v[(k0 + j) * st] = t[j];
             }
             // x_{N-1} = d*_{N-1}, x_i = d*_i - c*_i x_{i+1}                                (mnist_test.py:187-196)
-            for (int k = N - 2; k >= 0; --k) {
-                prev = v[k * st] - f[plane + (size_t)k * N + tid] * prev;
-                v[k * st] = prev;
+            for (int k0 = N - 2; k0 >= 0; k0 -= kGenBatch) {
+                float t[kGenBatch], cs[kGenBatch];
+#pragma unroll
+                for (int j = 0; j < kGenBatch; ++j) {
+                    const int k = k0 - j >= 0 ? k0 - j : 0;
+                    t[j] = v[k * st];
+                    cs[j] = f[plane + (size_t)k * N];
+                }
+#pragma unroll
+                for (int j = 0; j < kGenBatch; ++j)
+                    if (k0 - j >= 0) { prev = t[j] - cs[j] * prev; t[j] = prev; }
+#pragma unroll
+                for (int j = 0; j < kGenBatch; ++j)
+                    if (k0 - j >= 0) v[(k0 - j) * st] = t[j];
             }
         }
         __syncthreads();
         if (a.ckpt && gen_ck_bit(a.ck, s)) {
             float* dst = a.ckpt + (size_t)gen_ck_slot(a.ck, s) * a.B * a.C * plane + pb;
-            for (int e = tid; e < N * N; e += T) dst[e] = X[(e / N) * ld + (e % N)];
+            for (int e = tid; e < NN; e += T) dst[e] = X[(e / N) * ld + (e % N)];
         }
     }
     if (a.out)
-        for (int e = tid; e < N * N; e += T) GenIo<IO>::st(a.out, pb + e, X[(e / N) * ld + (e % N)]);
+        for (int e = tid; e < NN; e += T) GenIo<IO>::st(a.out, pb + e, X[(e / N) * ld + (e % N)]);
 }
 
 // backward: workgroup (c, g) walks the planes b = g, g+G, ... of channel c; adjoint in R, state in X (both LDS);
-// parameter-gradient partial sums in part[g][c][arr][N*N], every entry owned by one thread of this workgroup
-template <typename IO>
+// parameter-gradient partial sums in part[g][c][arr][N*N], every entry owned by one thread of this workgroup.
+// ALDS: the four partial-sum images live in LDS beside the two planes and go to `part` once, at the end (chosen while four
+// workgroups still fit on a CU, see the launch); otherwise every update is a read-modify-write of global memory by the
+// owning thread.
+template <typename IO, bool ALDS>
 __global__ void gen_bwd_kernel(GenSweepArgs a, int smooth3) {
-    extern __shared__ float smem[];
-    const int N = a.N, ld = N + 1, tid = threadIdx.x, T = blockDim.x;
-    float* X = smem;
-    float* R = smem + (size_t)N * ld;
-    const size_t plane = (size_t)N * N;
+    extern __shared__ float gen_smem[];
+    const int N = a.N, ld = N + 1, tid = threadIdx.x, T = blockDim.x, NN = N * N;
+    float* X = gen_smem;
+    float* R = X + (size_t)N * ld;
+    float* ACC = R + (size_t)N * ld;                      // ALDS: [4][N][ld], indexed like the planes
+    const size_t plane = (size_t)NN;
     const int c = blockIdx.x % a.C, g = blockIdx.x / a.C;
     float* part = a.part + ((size_t)g * a.C + c) * 4 * plane;
-    for (size_t e = tid; e < 4 * plane; e += T) part[e] = 0.f;
+    if constexpr (ALDS) {
+        for (int e = tid; e < 4 * N * ld; e += T) ACC[e] = 0.f;
+    } else {
+        for (size_t e = tid; e < 4 * plane; e += T) part[e] = 0.f;
+    }
     const float one_eps = 1.0f + a.eps, third = 1.0f / 3.0f;
     for (int b = g; b < a.B; b += a.G) {
         const size_t pb = ((size_t)b * a.C + c) * plane;
         __syncthreads();
-        for (int e = tid; e < N * N; e += T) {
+        for (int e = tid; e < NN; e += T) {
             R[(e / N) * ld + (e % N)] = GenIo<IO>::ld(a.in0, pb + e);
             X[(e / N) * ld + (e % N)] = GenIo<IO>::ld(a.in1, pb + e);
         }
@@ -176,79 +213,139 @@ __global__ void gen_bwd_kernel(GenSweepArgs a, int smooth3) {
         for (int s = a.S - 1; s >= 0; --s) {
             const GenSweep sw = a.tab[s];
             if (tid < N) {
-                const float* f = a.fac + ((size_t)s * a.C + c) * kGenArr * plane;
+                const float* __restrict__ f = a.fac + ((size_t)s * a.C + c) * kGenArr * plane + tid;   // [arr][k][line = tid]
                 const bool xs = sw.axis == PDE_AXIS_X;
                 float* r = R + (xs ? tid * ld : tid);
                 float* x = X + (xs ? tid * ld : tid);
                 const int st = xs ? 1 : ld;
                 // transposed recurrences: U^T w = r (unit lower, sub-diagonal c*), L^T lam = w (diagonal den, super-diagonal a)
                 float prev = r[0];
-                for (int k = 1; k < N; ++k) {
-                    prev = r[k * st] - f[plane + (size_t)(k - 1) * N + tid] * prev;
-                    r[k * st] = prev;
+                for (int k0 = 1; k0 < N; k0 += kGenBatch) {
+                    float t[kGenBatch], cs[kGenBatch];
+#pragma unroll
+                    for (int j = 0; j < kGenBatch; ++j) {
+                        const int k = k0 + j < N ? k0 + j : N - 1;
+                        t[j] = r[k * st];
+                        cs[j] = f[plane + (size_t)(k - 1) * N];
+                    }
+#pragma unroll
+                    for (int j = 0; j < kGenBatch; ++j)
+                        if (k0 + j < N) { prev = t[j] - cs[j] * prev; t[j] = prev; }
+#pragma unroll
+                    for (int j = 0; j < kGenBatch; ++j)
+                        if (k0 + j < N) r[(k0 + j) * st] = t[j];
                 }
-                prev = prev * f[2 * plane + (size_t)(N - 1) * N + tid];
+                prev = prev * f[2 * plane + (size_t)(N - 1) * N];
                 r[(N - 1) * st] = prev;
-                for (int k = N - 2; k >= 0; --k) {
-                    prev = (r[k * st] + f[(size_t)(k + 1) * N + tid] * prev) * f[2 * plane + (size_t)k * N + tid];
-                    r[k * st] = prev;
+                for (int k0 = N - 2; k0 >= 0; k0 -= kGenBatch) {
+                    float t[kGenBatch], co[kGenBatch], iv[kGenBatch];
+#pragma unroll
+                    for (int j = 0; j < kGenBatch; ++j) {
+                        const int k = k0 - j >= 0 ? k0 - j : 0;
+                        t[j] = r[k * st];
+                        co[j] = f[(size_t)(k + 1) * N];
+                        iv[j] = f[2 * plane + (size_t)k * N];
+                    }
+#pragma unroll
+                    for (int j = 0; j < kGenBatch; ++j)
+                        if (k0 - j >= 0) { prev = (t[j] + co[j] * prev) * iv[j]; t[j] = prev; }
+#pragma unroll
+                    for (int j = 0; j < kGenBatch; ++j)
+                        if (k0 - j >= 0) r[(k0 - j) * st] = t[j];
                 }
                 // coefficient gradient -lam.q with the sweep's OUTPUT state, q = (Neumann second difference, sign flipped);
                 // x_old = (1+eps) x + coeff q; then the transposed smoothing (entry j is complete once k = j+1 is known),
                 // the clamp mask, and the two parameters: d/d base, d/d slope = t * d/d base
-                float* pbase = part + (xs ? 0 : 2) * plane;
-                float* pslope = pbase + plane;
-                const int pl = xs ? tid * N : tid, pk = xs ? 1 : N;        // parameter index of (line, k)
-                float xm = 0.f, xc = x[0], g2 = 0.f, g1 = 0.f;            // x_{k-1}, x_k; gsm_{k-2}, gsm_{k-1}
-                for (int k = 0; k < N; ++k) {
-                    const float xp = (k + 1 < N) ? x[(k + 1) * st] : 0.f;
-                    const float q = ((k == 0 || k == N - 1) ? xc : 2.0f * xc) - xm - xp;
-                    const size_t o = (size_t)k * N + tid;
-                    const float g0 = -r[k * st] * q * sw.scale;
-                    x[k * st] = one_eps * xc + f[o] * q;
-                    xm = xc;
-                    xc = xp;
-                    if (!smooth3) {
-                        const float gv = g0 * f[3 * plane + o];
-                        pbase[pl + k * pk] += gv;
-                        pslope[pl + k * pk] += sw.t * gv;
-                    } else if (k >= 1) {                                   // finish entry j = k-1
-                        const int j = k - 1;
-                        float gv = (g2 * third + g1 * third) + g0 * third;
-                        if (j == 0) gv += g1 * third;                      // replicate end: theta_0 is used twice by sm_0
-                        gv *= f[3 * plane + (size_t)j * N + tid];
+                float* __restrict__ pbase = part + (xs ? 0 : 2) * plane;
+                float* __restrict__ pslope = pbase + plane;
+                // partial sums in global memory are kept [k][line] for BOTH axes (threads of a wave then touch consecutive
+                // words; [line][k] made every x-sweep update a cache line of its own): the alpha images are stored
+                // transposed and gen_reduce_kernel turns them back
+                const int pl = tid, pk = N;
+                float* lbase = ACC + (xs ? 0 : 2) * N * ld + (xs ? tid * ld : tid);
+                auto add = [&](int j, float gv) __attribute__((always_inline)) {
+                    if constexpr (ALDS) {
+                        lbase[j * st] += gv;
+                        lbase[N * ld + j * st] += sw.t * gv;
+                    } else {
                         pbase[pl + j * pk] += gv;
                         pslope[pl + j * pk] += sw.t * gv;
                     }
-                    g2 = g1;
-                    g1 = g0;
+                };
+                float xm = 0.f, xc = x[0], g2 = 0.f, g1 = 0.f;            // x_{k-1}, x_k; gsm_{k-2}, gsm_{k-1}
+                for (int k0 = 0; k0 < N; k0 += kGenBatch) {
+                    float xn[kGenBatch], lam[kGenBatch], co[kGenBatch], ps[kGenBatch], gout[kGenBatch];
+#pragma unroll
+                    for (int j = 0; j < kGenBatch; ++j) {
+                        const int k = k0 + j < N ? k0 + j : N - 1;
+                        xn[j] = (k0 + j + 1 < N) ? x[(k0 + j + 1) * st] : 0.f;      // x_{k+1}
+                        lam[j] = r[k * st];
+                        co[j] = f[(size_t)k * N];
+                        ps[j] = f[3 * plane + (size_t)k * N];
+                    }
+                    const float ps_before = k0 > 0 ? f[3 * plane + (size_t)(k0 - 1) * N] : 0.f;   // mask of entry k0-1 (smoothing)
+#pragma unroll
+                    for (int j = 0; j < kGenBatch; ++j) {
+                        const int k = k0 + j;
+                        gout[j] = 0.f;
+                        if (k < N) {
+                            const float xp = xn[j];
+                            const float q = ((k == 0 || k == N - 1) ? xc : 2.0f * xc) - xm - xp;
+                            const float g0 = -lam[j] * q * sw.scale;
+                            xn[j] = one_eps * xc + co[j] * q;                       // becomes x_old[k]
+                            xm = xc;
+                            xc = xp;
+                            if (!smooth3) {
+                                gout[j] = g0 * ps[j];                               // entry k
+                            } else if (k >= 1) {                                    // finishes entry k-1
+                                float gv = (g2 * third + g1 * third) + g0 * third;
+                                if (k == 1) gv += g1 * third;                       // replicate end: theta_0 is used twice by sm_0
+                                gout[j] = gv * (j > 0 ? ps[j - 1] : ps_before);
+                            }
+                            g2 = g1;
+                            g1 = g0;
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < kGenBatch; ++j) {
+                        const int k = k0 + j;
+                        if (k < N) {
+                            x[k * st] = xn[j];
+                            if (!smooth3) add(k, gout[j]);
+                            else if (k >= 1) add(k - 1, gout[j]);
+                        }
+                    }
                 }
                 if (smooth3) {                                             // entry N-1: (gsm_{N-2} + 2 gsm_{N-1}) / 3
-                    float gv = (g2 * third + g1 * third) + g1 * third;
-                    gv *= f[3 * plane + (size_t)(N - 1) * N + tid];
-                    pbase[pl + (N - 1) * pk] += gv;
-                    pslope[pl + (N - 1) * pk] += sw.t * gv;
+                    const float gv = (g2 * third + g1 * third) + g1 * third;
+                    add(N - 1, gv * f[3 * plane + (size_t)(N - 1) * N]);
                 }
             }
             __syncthreads();
             if (s > 0 && a.ckpt && gen_ck_bit(a.ck, s - 1)) {             // the parked state instead of the rebuilt one
                 const float* src = a.ckpt + (size_t)gen_ck_slot(a.ck, s - 1) * a.B * a.C * plane + pb;
-                for (int e = tid; e < N * N; e += T) X[(e / N) * ld + (e % N)] = src[e];
+                for (int e = tid; e < NN; e += T) X[(e / N) * ld + (e % N)] = src[e];
                 __syncthreads();
             }
         }
-        for (int e = tid; e < N * N; e += T) GenIo<IO>::st(a.out, pb + e, R[(e / N) * ld + (e % N)]);
+        for (int e = tid; e < NN; e += T) GenIo<IO>::st(a.out, pb + e, R[(e / N) * ld + (e % N)]);
+    }
+    if constexpr (ALDS) {
+        __syncthreads();
+        for (int arr = 0; arr < 4; ++arr)
+            for (int e = tid; e < NN; e += T)              // alpha images transposed, as above
+                part[arr * plane + e] = ACC[arr * N * ld + (arr < 2 ? (e % N) * ld + (e / N) : (e / N) * ld + (e % N))];
     }
 }
 
 // the four parameter gradients: partial sums added over the groups in a fixed order
-__global__ void gen_reduce_kernel(const float* part, int G, int C, int NN, float* g_ab, float* g_as, float* g_bb, float* g_bs) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void gen_reduce_kernel(const float* part, int G, int C, int N, float* g_ab, float* g_as, float* g_bb, float* g_bs) {
+    const int NN = N * N, e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= C * NN) return;
-    const int c = e / NN, p = e % NN;
+    const int c = e / NN, p = e % NN, pt = (p % N) * N + p / N;        // the alpha images are stored transposed
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     for (int g = 0; g < G; ++g)
-        for (int arr = 0; arr < 4; ++arr) s[arr] += part[(((size_t)g * C + c) * 4 + arr) * NN + p];
+        for (int arr = 0; arr < 4; ++arr) s[arr] += part[(((size_t)g * C + c) * 4 + arr) * NN + (arr < 2 ? pt : p)];
     g_ab[e] = s[0]; g_as[e] = s[1]; g_bb[e] = s[2]; g_bs[e] = s[3];
 }
 
@@ -273,7 +370,7 @@ int launch_gen_factor(const PdeAdiDesc* d, const float* ab, const float* bb, con
     return check_launch();
 }
 
-constexpr int kGenLdsMax = 2 * 128 * 129 * (int)sizeof(float);
+constexpr int kGenLdsMax = 160 * 1024;        // the CU's LDS (two 128 x 129 planes are 132 KB)
 template <typename K>
 int gen_lds(K kernel, unsigned long long& done) { return ensure_dynamic_lds((const void*)kernel, kGenLdsMax, done); }
 
@@ -353,18 +450,25 @@ int gen_backward(const PdeAdiDesc* d, const void* gy, const void* y, const void*
     sa.in0 = gy; sa.in1 = y; sa.out = gu; sa.fac = fac; sa.tab = tab; sa.ckpt = ckpt; sa.part = part;
     sa.ck[0] = nck ? ckpt_mask[0] : 0ull; sa.ck[1] = nck ? ckpt_mask[1] : 0ull;
     sa.B = d->B; sa.C = d->C; sa.N = d->N; sa.S = d->num_sweeps; sa.G = G; sa.eps = d->eps;
-    const size_t lds = (size_t)2 * d->N * (d->N + 1) * sizeof(float);
-    static unsigned long long done_f = 0, done_b = 0;
+    const size_t img = (size_t)d->N * (d->N + 1) * sizeof(float);
+    const bool alds = 4 * 6 * img <= (size_t)kGenLdsMax;  // the partial sums beside the planes while four workgroups fit on a CU (N <= 40)
+    const size_t lds = (alds ? 6 : 2) * img;
+    static unsigned long long done[4] = {0, 0, 0, 0};
+    const dim3 grid(G * d->C), block(gen_threads(d->N));
+#define PDE_GEN_BWD(IO, AL, SLOT)                                                                        \
+    do {                                                                                                 \
+        if ((rc = gen_lds(gen_bwd_kernel<IO, AL>, done[SLOT])) != PDE_OK) return rc;                     \
+        hipLaunchKernelGGL((gen_bwd_kernel<IO, AL>), grid, block, lds, st, sa, (int)d->smooth3);         \
+    } while (0)
     if (d->io_dtype == PDE_IO_F32) {
-        if ((rc = gen_lds(gen_bwd_kernel<float>, done_f)) != PDE_OK) return rc;
-        hipLaunchKernelGGL(gen_bwd_kernel<float>, dim3(G * d->C), dim3(gen_threads(d->N)), lds, st, sa, (int)d->smooth3);
+        if (alds) PDE_GEN_BWD(float, true, 0); else PDE_GEN_BWD(float, false, 1);
     } else {
-        if ((rc = gen_lds(gen_bwd_kernel<gen_bf16>, done_b)) != PDE_OK) return rc;
-        hipLaunchKernelGGL(gen_bwd_kernel<gen_bf16>, dim3(G * d->C), dim3(gen_threads(d->N)), lds, st, sa, (int)d->smooth3);
+        if (alds) PDE_GEN_BWD(gen_bf16, true, 2); else PDE_GEN_BWD(gen_bf16, false, 3);
     }
+#undef PDE_GEN_BWD
     if ((rc = check_launch()) != PDE_OK) return rc;
     const int NN = d->N * d->N, total = d->C * NN;
-    hipLaunchKernelGGL(gen_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, part, G, d->C, NN, g_ab, g_as, g_bb, g_bs);
+    hipLaunchKernelGGL(gen_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, part, G, d->C, d->N, g_ab, g_as, g_bb, g_bs);
     return check_launch();
 }
 

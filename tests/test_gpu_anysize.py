@@ -54,9 +54,11 @@ def test_every_layer_class_vs_oracle(N):
     _compare(ly, lambda a, p: O.adi_forward(a, p, O.svhn_spec(N, 4, 0.05, 1.0, 2)), u, gy)
 
 
-@pytest.mark.parametrize("N", [100, 128])
+@pytest.mark.parametrize("N", [82, 84, 100, 104, 128])
 def test_longest_lines(N):
-    """Two threads' worth of waves per plane, more than 64 KB of LDS per workgroup."""
+    """Two waves per plane, more than 64 KB of LDS per workgroup.  The kernels keep what fits in LDS beside the planes: the
+    sweep's factorisation up to N = 100 forward / 82 backward (both sides of both limits here), the partial gradient sums up
+    to N = 44 (test_every_layer_class_vs_oracle and the random walk have sizes on both sides)."""
     import cnn_with_pde_amd as P
     g = torch.Generator().manual_seed(77 + N)
     ly = quiet(P.EnhancedDiffusionLayer, N, 2, dt=0.02, num_steps=2, channel_mixing_enabled=False)
