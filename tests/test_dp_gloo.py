@@ -19,6 +19,32 @@ def _free_port():
     return p
 
 
+def _launch(world, worker, timeout):
+    """Start `world` ranks on 127.0.0.1 and return what rank 0 puts on the queue.  The rendezvous port is picked by binding
+    port 0 and releasing it, which another process can win in between: one more attempt on a fresh port in that case."""
+    import queue
+    ctx = mp.get_context("spawn")
+    last = None
+    for attempt in range(2):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        try:
+            got = q.get(timeout=timeout)
+        except queue.Empty as e:
+            got, last = None, e
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.terminate()
+        if got is not None and all(p.exitcode == 0 for p in procs):
+            return got
+        last = last or RuntimeError(f"rank exit codes {[p.exitcode for p in procs]}")
+    raise last
+
+
 def _worker(rank, world, port, q):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -48,16 +74,7 @@ def _worker(rank, world, port, q):
 
 def test_two_rank_allreduce_matches_full_batch():
     from oracle import pde_oracle as O
-    world, port = 2, _free_port()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    got = q.get(timeout=120)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    got = _launch(2, _worker, 120)
     spec = O.cifar10_spec(8, 2, dt=0.05, num_steps=2)
     g = torch.Generator().manual_seed(11)
     params = {k: v.clone().requires_grad_(True) for k, v in O.adi_init_params(spec, "cifar10", gen=g).items()}
@@ -105,16 +122,7 @@ def _worker4(rank, world, port, q):
 
 def test_four_ranks_ragged_batch_sum_semantics_views_and_hooks():
     from oracle import pde_oracle as O
-    world, port = 4, _free_port()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker4, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    got = q.get(timeout=180)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    got = _launch(4, _worker4, 180)
     spec = O.cifar10_spec(8, 2, dt=0.05, num_steps=2)
     g = torch.Generator().manual_seed(12)
     params = {k: v.clone().requires_grad_(True) for k, v in O.adi_init_params(spec, "cifar10", gen=g).items()}
