@@ -63,6 +63,12 @@ int mix_bf16_apply(int B, int C, int HW, const void* u, const float* M, void* ou
 int mix_bf16_backward(int B, int C, int HW, const void* u, const void* g, const float* M, void* gu, float* part, int nsplit,
                       int accp, hipStream_t st);
 
+// fp32 tensors through the bf16 MFMA with every operand as three bf16 pieces (pde_mix_bf16.hip); C = 64, HW a multiple of 64
+bool mix_split_ok(int C, int HW);
+int mix_split_splits(int B, int C, int HW);
+int mix_split_backward(int B, int C, int HW, const void* u, const void* g, const float* M, void* gu, float* part, int nsplit,
+                       int accp, hipStream_t st);
+
 // fp32 -> bf16, round to nearest even: one v_cvt_pk_bf16_f32 per pair on gfx950 (the bit-twiddling form costs
 // five VALU instructions per element, and a VALU instruction is what the sweep kernels run out of)
 __device__ __forceinline__ unsigned short f32_to_bf16_hw(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }

@@ -522,6 +522,7 @@ size_t pde_channel_mix_backward_workspace_bytes(int32_t B, int32_t C, int32_t HW
     if (mfma_fused_ok(C, HW)) n = n > fused_splits(B, C, HW) ? n : fused_splits(B, C, HW);
     if (mfma_gm_ok(C, HW)) n = n > gm_mfma_splits(B, HW) ? n : gm_mfma_splits(B, HW);
     if (mix_bf16_ok(C, HW)) n = n > mix_bf16_splits(B, C, HW) ? n : mix_bf16_splits(B, C, HW);
+    if (mix_split_ok(C, HW)) n = n > mix_split_splits(B, C, HW) ? n : mix_split_splits(B, C, HW);
     return (size_t)(n + 1) * C * C * sizeof(float);      // partial matrices + one fragment table
 }
 
@@ -546,6 +547,13 @@ int pde_channel_mix_backward_steps(int32_t B, int32_t C, int32_t HW, int32_t io_
     if (io_dtype == PDE_IO_BF16 && mix_bf16_ok(C, HW)) {   // exact bf16 products on the bf16 MFMA
         const int nsplit = mix_bf16_splits(B, C, HW);
         const int rc = mix_bf16_backward(B, C, HW, u, gout, M, gu, part, nsplit, accumulate, st);
+        if (rc != PDE_OK) return rc;
+        if (finalize) hipLaunchKernelGGL(mix_gm_reduce_kernel, dim3((C * C + 31) / 32), dim3(256), 0, st, part, gM, C * C, nsplit);
+        return check_launch();
+    }
+    if (io_dtype == PDE_IO_F32 && mix_split_ok(C, HW)) {   // fp32 tensors, three bf16 pieces per operand on the bf16 MFMA
+        const int nsplit = mix_split_splits(B, C, HW);
+        const int rc = mix_split_backward(B, C, HW, u, gout, M, gu, part, nsplit, accumulate, st);
         if (rc != PDE_OK) return rc;
         if (finalize) hipLaunchKernelGGL(mix_gm_reduce_kernel, dim3((C * C + 31) / 32), dim3(256), 0, st, part, gM, C * C, nsplit);
         return check_launch();

@@ -246,6 +246,165 @@ __global__ __launch_bounds__(C * 4) void mix_bwd_bf16_kernel(const unsigned shor
     }
 }
 
+// ---- fp32 tensors on the bf16 matrix cores: every operand as THREE bf16 pieces -------------------------------------
+// x = hi + mid + lo with hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid): 3 x 8 mantissa bits, the remainder is
+// below 2^-24 |x|.  A product a b is taken as the six piece products of order <= 2 (hi hi, hi mid, mid hi, hi lo, lo hi,
+// mid mid; the dropped ones are below 2^-24 |a b|), each EXACT in the MFMA's fp32 accumulation: fp32-level accuracy at
+// 6/16 of the fp32 MFMA's time (v_mfma_f32_32x32x16_bf16 does 16 k-steps in 32 cycles, v_mfma_f32_32x32x2_f32 2 in 64).
+// Same structure as mix_bwd_bf16_kernel: a [C][64 px] tile of g and u, split once when it is deposited in LDS (three
+// natural-layout images per tensor), both products from there; the result tile goes out through an fp32 image that reuses
+// the space of two u images.  C = 64: 24 KB of M fragments + 54 KB of images: two workgroups per CU.
+constexpr int kRowF = 272;              // bytes per row of the fp32 result image: 256 + 16 pad
+
+__device__ __forceinline__ void split3(float x, unsigned short& hi, unsigned short& mid, unsigned short& lo) {
+    hi = f2bf(x);
+    const float r1 = x - bf2f(hi);
+    mid = f2bf(r1);
+    lo = f2bf(r1 - bf2f(mid));
+}
+
+template <int C>
+__device__ __forceinline__ void build_frags3(const float* __restrict__ M, unsigned short* frag, int tid, int nthreads) {
+    // B[k = out i][col = in j] = M[i][j] (backward): lane (h,r) of (jt,ks): M[16ks + 8h + jj][32jt + r]; [piece][tile][ks][lane][8]
+    constexpr int T = C / 32, KS = C / 16, FR = T * KS * 64;
+    for (int e = tid; e < FR; e += nthreads) {
+        const int lane = e & 63, ks = (e >> 6) % KS, t = (e >> 6) / KS;
+        const int h = lane >> 5, r = lane & 31;
+        unsigned short p[3][8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) split3(M[(16 * ks + 8 * h + jj) * C + 32 * t + r], p[0][jj], p[1][jj], p[2][jj]);
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            *reinterpret_cast<uint4*>(frag + ((size_t)q * FR + e) * 8) =
+                make_uint4(p[q][0] | (p[q][1] << 16), p[q][2] | (p[q][3] << 16), p[q][4] | (p[q][5] << 16), p[q][6] | (p[q][7] << 16));
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(C * 4) void mix_bwd_split_kernel(const float* __restrict__ u, const float* __restrict__ g,
+                                                              const float* __restrict__ M, float* __restrict__ gu,
+                                                              float* __restrict__ part, int B, int HW, int accp) {
+    constexpr int T = C / 32, KS = C / 16, NT = C * 4, W = C / 16, FR = T * KS * 64;
+    constexpr int NTM = T * T / W;                         // gM tiles per wave (C = 64: 1)
+    constexpr int IMG = C * kRow;                          // bytes of one bf16 image
+    constexpr int PCS = C * 16 / NT;                       // 16-byte pieces of an fp32 tile per thread (4)
+    static_assert(2 * IMG >= C * kRowF, "the result image fits in two piece images");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned short* frag = reinterpret_cast<unsigned short*>(smem);          // [3][FR][8] bf16 = 6*C*C bytes
+    unsigned char* img_g = smem + (size_t)6 * C * C;                          // [3][C][kRow]
+    unsigned char* img_u = img_g + 3 * IMG;                                   // [3][C][kRow]
+    unsigned char* img_o = img_u + IMG;                                       // fp32 result over u's mid and lo images
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, r = lane & 31;
+    build_frags3<C>(M, frag, tid, NT);
+    const int pg = wave & 1, jt = wave >> 1;               // my gu tile: pixel group, input-channel tile
+    f32x16 acc_m[NTM];
+#pragma unroll
+    for (int t = 0; t < NTM; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc_m[t][i] = 0.f;
+    const int per_sample = HW / kPx;
+    const long total = (long)B * per_sample;
+    float4 gq[PCS], uq[PCS];
+    auto fetch = [&](long tile) __attribute__((always_inline)) {
+        const size_t o = (size_t)(tile / per_sample) * C * HW;
+        const int q0 = (int)(tile % per_sample) * kPx;
+#pragma unroll
+        for (int i = 0; i < PCS; ++i) {
+            const int e = tid + i * NT, row = e >> 4, c4 = e & 15;
+            gq[i] = *reinterpret_cast<const float4*>(g + o + (size_t)row * HW + q0 + 4 * c4);
+            uq[i] = *reinterpret_cast<const float4*>(u + o + (size_t)row * HW + q0 + 4 * c4);
+        }
+    };
+    auto deposit = [&](const float4 (&q)[PCS], unsigned char* img) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PCS; ++i) {
+            const int e = tid + i * NT, row = e >> 4, c4 = e & 15;
+            const float v[4] = {q[i].x, q[i].y, q[i].z, q[i].w};
+            unsigned short p[3][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) split3(v[j], p[0][j], p[1][j], p[2][j]);
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+                *reinterpret_cast<uint2*>(img + s * IMG + row * kRow + 8 * c4) = make_uint2(p[s][0] | (p[s][1] << 16), p[s][2] | (p[s][3] << 16));
+        }
+    };
+    if ((long)blockIdx.x < total) fetch(blockIdx.x);
+    for (long tile = blockIdx.x; tile < total; tile += gridDim.x) {
+        const int b = (int)(tile / per_sample), p0 = (int)(tile % per_sample) * kPx;
+        __syncthreads();                                   // fragments built / previous tile's images consumed and stored
+        deposit(gq, img_g);
+        deposit(uq, img_u);
+        __syncthreads();
+        const long tn = tile + gridDim.x;
+        if (tn < total) fetch(tn);                         // the next tile's loads fly during this tile's MFMAs
+        // gM: contraction over the 64 pixels of the tile, 16 per MFMA, six piece products
+#pragma unroll
+        for (int kp = 0; kp < kPx / 16; ++kp) {
+#pragma unroll
+            for (int t = 0; t < NTM; ++t) {
+                const int tl = wave + W * t, it = tl / T, jt2 = tl % T;
+                v8bf a[3], bb[3];
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    a[s] = row_operand(img_g + s * IMG, 32 * it + r, 16 * kp + 8 * h);
+                    bb[s] = row_operand(img_u + s * IMG, 32 * jt2 + r, 16 * kp + 8 * h);
+                }
+                acc_m[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bb[1], acc_m[t], 0, 0, 0);   // smallest terms first
+                acc_m[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bb[2], acc_m[t], 0, 0, 0);
+                acc_m[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], bb[0], acc_m[t], 0, 0, 0);
+                acc_m[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bb[1], acc_m[t], 0, 0, 0);
+                acc_m[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bb[0], acc_m[t], 0, 0, 0);
+                acc_m[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bb[0], acc_m[t], 0, 0, 0);
+            }
+        }
+        // gu^T tile = g^T M, pieces of g against pieces of M
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll 2
+        for (int ks = 0; ks < KS; ++ks) {
+            const int fi = (jt * KS + ks) * 64 + lane;
+            v8bf a[3], f[3];
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                a[s] = tr_operand(img_g + s * IMG, pg, ks, lane);
+                f[s] = frag_operand(frag, s * FR + fi);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], f[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], f[2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], f[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], f[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], f[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], f[0], acc, 0, 0, 0);
+        }
+        __syncthreads();                                   // every wave is done with the u images: the result goes over two of them
+        // D tile [pixel][channel]: lane (h,r) holds channel 32 jt + r, pixels 32pg + 8q + 4h + 0..3 in regs 4q..4q+3
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(img_o + (32 * jt + r) * kRowF + (32 * pg + 8 * q + 4 * h) * 4) =
+                make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < PCS; ++i) {
+            const int e = tid + i * NT, row = e >> 4, c4 = e & 15;
+            *reinterpret_cast<float4*>(gu + (size_t)b * C * HW + (size_t)row * HW + p0 + 4 * c4) =
+                *reinterpret_cast<const float4*>(img_o + row * kRowF + 16 * c4);
+        }
+    }
+    float* dst = part + (size_t)blockIdx.x * C * C;
+#pragma unroll
+    for (int t = 0; t < NTM; ++t) {
+        const int tl = wave + W * t, it = tl / T, jt2 = tl % T;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int i = 32 * it + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            float* o = dst + i * C + 32 * jt2 + r;
+            *o = accp ? *o + acc_m[t][reg] : acc_m[t][reg];
+        }
+    }
+}
+
 inline void ensure_lds(const void* kernel, int bytes, unsigned long long& done) { (void)ensure_dynamic_lds(kernel, bytes, done); }
 
 template <int C>
@@ -269,7 +428,32 @@ void launch_bwd(const void* u, const void* g, const float* M, void* gu, float* p
                        (const unsigned short*)g, M, (unsigned short*)gu, part, B, HW, accp);
 }
 
+template <int C>
+void launch_split(const void* u, const void* g, const float* M, void* gu, float* part, int B, int HW, int nsplit, int accp,
+                  hipStream_t st) {
+    const size_t lds = (size_t)6 * C * C + 6 * (size_t)C * kRow;
+    static unsigned long long cfg = 0;
+    ensure_lds((const void*)mix_bwd_split_kernel<C>, (int)lds, cfg);
+    hipLaunchKernelGGL((mix_bwd_split_kernel<C>), dim3((unsigned)nsplit), dim3(C * 4), lds, st, (const float*)u, (const float*)g, M,
+                       (float*)gu, part, B, HW, accp);
+}
+
 }  // namespace
+
+// fp32 tensors through the bf16 matrix cores, three pieces per operand (C = 64, HW a multiple of 64)
+bool mix_split_ok(int C, int HW) {
+    return C == 64 && (HW % kPx) == 0 && getenv("PDE_MIX_NO_SPLIT") == nullptr;
+}
+int mix_split_splits(int B, int C, int HW) {
+    const long tiles = (long)B * (HW / kPx);
+    const long want = 512;                                 // two resident workgroups per CU (78 KB of LDS each)
+    return (int)(tiles < want ? tiles : want);
+}
+int mix_split_backward(int B, int C, int HW, const void* u, const void* g, const float* M, void* gu, float* part, int nsplit,
+                       int accp, hipStream_t st) {
+    launch_split<64>(u, g, M, gu, part, B, HW, nsplit, accp, st);
+    return check_launch();
+}
 
 // entry points used by pde_mix.hip (same shared library)
 bool mix_bf16_ok(int C, int HW) {
