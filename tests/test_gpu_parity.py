@@ -272,6 +272,31 @@ def test_channel_mix_vs_fp64(C, HW):
     assert G.rel_err(Md.grad.cpu(), M64.grad) <= TOL
 
 
+@pytest.mark.parametrize("B,HW,scale", [(5, 1024, 0.1), (64, 1024, 0.3), (7, 64, 1.0), (1, 4096, 0.05)])
+def test_channel_mix_three_piece_products(B, HW, scale):
+    """fp32 tensors at C = 64 run the operator's backward on the bf16 matrix cores with every operand as three bf16 pieces
+    (pde_mix_bf16.hip: mix_bwd_split_kernel).  That must be fp32 arithmetic to the last bits, not bf16 arithmetic: against
+    fp64, with six decades of dynamic range across the channels of the incoming gradient, tighter than the 1e-5 of the
+    other paths (measured 6-9e-8 and 2-4e-7; torch's own fp32 matmul is at 7e-8 and 3-7e-7)."""
+    import cnn_with_pde_amd as P
+    C = 64
+    g = torch.Generator().manual_seed(1000 + B)
+    u = torch.randn(B, C, HW, generator=g)
+    M = torch.eye(C) + scale * torch.randn(C, C, generator=g)
+    go = torch.randn(B, C, HW, generator=g) * torch.logspace(-3, 3, C).view(1, C, 1)
+    ud, Md = u.cuda().requires_grad_(True), M.cuda().requires_grad_(True)
+    out = P.channel_mix(ud.view(B, C, HW, 1), Md)
+    out.backward(go.view(B, C, HW, 1).cuda())
+    u64, M64 = u.double().requires_grad_(True), M.double().requires_grad_(True)
+    ref = torch.matmul(M64, u64)
+    ref.backward(go.double())
+    assert G.rel_err(ud.grad.cpu().double(), u64.grad) <= 5e-7
+    assert G.rel_err(Md.grad.cpu().double(), M64.grad) <= 2e-6
+    # per-channel accuracy too: a small channel of gu must not drown in the rounding of a large one
+    per = ((ud.grad.cpu().double() - u64.grad).abs().amax(dim=(0, 2)) / u64.grad.abs().amax(dim=(0, 2))).max()
+    assert float(per) <= 2e-6, float(per)
+
+
 @pytest.mark.parametrize("C", [64, 128, 32])
 def test_channel_mix_bf16_io(C):
     """bf16 tensors through the MFMA mixing kernels (C = 64/128: fused backward), fp32 arithmetic inside."""
