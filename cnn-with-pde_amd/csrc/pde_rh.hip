@@ -19,6 +19,8 @@
 // Boundary: plain pointers, caller-owned buffers, asynchronous on the given stream (include/pdecnn.h).
 #include "pde_common.h"
 
+#include <cstdlib>
+
 namespace pde {
 namespace {
 
@@ -473,6 +475,152 @@ __global__ __launch_bounds__(kRhThreads) void rh_outer_kernel(RhOuterArgs a) {
         }
 }
 
+// ---- the same gradient with every fp32 operand as three bf16 pieces on the bf16 matrix cores -----------------------------
+// (see pde_mix_bf16.hip: x = hi + mid + lo, the six piece products of order <= 2, each exact in the fp32 accumulator;
+// v_mfma_f32_32x32x16_bf16 does 16 contraction steps in 32 cycles where v_mfma_f32_32x32x2_f32 does 2 in 64.)
+// A slab is 16 batch rows — ONE contraction group — of the [64 | 192] features of the tile, split when it is deposited in
+// LDS as bf16 images [piece][batch row][feature]; both operands have the contraction index (batch) as the image's ROW, so both
+// come out through the transposing read ds_read_b64_tr_b16 (operand lane (h, r): feature r of its group of 32, batch rows
+// 8h .. 8h+7).  Double-buffered: one barrier per slab.
+typedef short rh_v4s __attribute__((ext_vector_type(4)));
+typedef short rh_v8s __attribute__((ext_vector_type(8)));
+typedef __bf16 rh_v8bf __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned short rh_f2bf(float f) { return f32_to_bf16_hw(f); }
+__device__ __forceinline__ float rh_bf2f(unsigned short h) { return __uint_as_float((unsigned int)h << 16); }
+// operand with k = the image's rows 0..15, the other index = features 32 fg .. 32 fg + 31 (PITCH bytes per row)
+template <int PITCH>
+__device__ __forceinline__ rh_v8bf rh_tr_operand(const unsigned char* img, int fg, int lane) {
+    const int grp = lane >> 4, i = lane & 15, h = lane >> 5;
+    const int q = i >> 2, p = i & 3;
+    const unsigned char* a0 = img + (8 * h + q) * PITCH + (32 * fg + 16 * (grp & 1) + 4 * p) * 2;
+    const rh_v4s lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((rh_v4s __attribute__((address_space(3)))*)(a0));
+    const rh_v4s hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((rh_v4s __attribute__((address_space(3)))*)(a0 + 4 * PITCH));
+    const rh_v8s all = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+    return __builtin_bit_cast(rh_v8bf, all);
+}
+
+// TI x TJ tile per workgroup, wave (wi, wj) a (TI/2) x (TJ/2) part = NI x NJ accumulators of 32 x 32
+template <int TI, int TJ>
+__global__ __launch_bounds__(kRhThreads) void rh_outer_split_kernel(RhOuterArgs a) {
+    constexpr int BKB = 16, NI = TI / 64, NJ = TJ / 64;
+    constexpr int PA = TI * 2 + 16, PB = TJ * 2 + 16;      // bytes per image row (16 bytes of padding)
+    constexpr int IA = 16 * PA, IB = 16 * PB;              // one piece, 16 batch rows
+    constexpr int BUF = 3 * (IA + IB);                     // one slab
+    constexpr int F4 = (TI + TJ) / 4;                      // float4 per batch row of the slab
+    constexpr int PT = BKB * F4 / kRhThreads;
+    static_assert(BKB * F4 % kRhThreads == 0 && TI % 64 == 0 && TJ % 64 == 0, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) unsigned char rh_spl[];   // [2][BUF]
+    unsigned char* S = rh_spl;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, jj = lane & 31, kh = lane >> 5;
+    const int i0 = blockIdx.y * TI, j0 = blockIdx.x * TJ;
+    const int wi = wave >> 1, wj = wave & 1;
+    f32x16 acc[NI][NJ];
+#pragma unroll
+    for (int p = 0; p < NI; ++p)
+#pragma unroll
+        for (int q = 0; q < NJ; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][q][r] = 0.f;
+    const int Bp = (a.B + BKB - 1) / BKB * BKB;
+    // (two slabs ahead of the matrix cores instead of one was tried: 84 us against 57 at 64 x 192)
+    float4 pv[PT];
+    auto fetch = [&](int v) __attribute__((always_inline)) {
+        const bool second = v >= Bp;
+        const float* A = second ? a.A2 : a.A1;
+        const float* Bm = second ? a.B2 : a.B1;
+#pragma unroll
+        for (int m = 0; m < PT; ++m) {
+            const int f = tid + kRhThreads * m, row = f / F4, c4 = f % F4;
+            const int b = (second ? v - Bp : v) + row;
+            pv[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b < a.B) {                                // (D is a multiple of 64: a float4 never straddles the edge)
+                if (c4 < TI / 4) {
+                    if (i0 + 4 * c4 < a.D) pv[m] = *reinterpret_cast<const float4*>(A + (size_t)b * a.D + i0 + 4 * c4);
+                } else if (j0 + 4 * (c4 - TI / 4) < a.D) {
+                    pv[m] = *reinterpret_cast<const float4*>(Bm + (size_t)b * a.D + j0 + 4 * (c4 - TI / 4));
+                    if (second) { pv[m].x *= a.s2; pv[m].y *= a.s2; pv[m].z *= a.s2; pv[m].w *= a.s2; }
+                }
+            }
+        }
+    };
+    auto stage = [&](int buf) __attribute__((always_inline)) {
+        unsigned char* base = S + buf * BUF;
+#pragma unroll
+        for (int m = 0; m < PT; ++m) {
+            const int f = tid + kRhThreads * m, row = f / F4, c4 = f % F4;
+            const float v[4] = {pv[m].x, pv[m].y, pv[m].z, pv[m].w};
+            unsigned short pc[3][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                pc[0][j] = rh_f2bf(v[j]);
+                const float r1 = v[j] - rh_bf2f(pc[0][j]);
+                pc[1][j] = rh_f2bf(r1);
+                pc[2][j] = rh_f2bf(r1 - rh_bf2f(pc[1][j]));
+            }
+            const bool isA = c4 < TI / 4;
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) {
+                unsigned char* dst = isA ? base + sp * IA + row * PA + 8 * c4
+                                         : base + 3 * IA + sp * IB + row * PB + 8 * (c4 - TI / 4);
+                *reinterpret_cast<uint2*>(dst) = make_uint2(pc[sp][0] | (pc[sp][1] << 16), pc[sp][2] | (pc[sp][3] << 16));
+            }
+        }
+    };
+    const int total = 2 * Bp;
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    int buf = 0;
+    for (int v = 0; v < total; v += BKB) {
+        const bool more = v + BKB < total;
+        if (more) fetch(v + BKB);
+        const unsigned char* ia = S + buf * BUF;
+        const unsigned char* ib = ia + 3 * IA;
+        rh_v8bf af[NI][3];
+#pragma unroll
+        for (int p = 0; p < NI; ++p)
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) af[p][sp] = rh_tr_operand<PA>(ia + sp * IA, wi * NI + p, lane);
+#pragma unroll
+        for (int q = 0; q < NJ; ++q) {
+            rh_v8bf bf[3];
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) bf[sp] = rh_tr_operand<PB>(ib + sp * IB, wj * NJ + q, lane);
+#pragma unroll
+            for (int p = 0; p < NI; ++p) {
+                acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[p][1], bf[1], acc[p][q], 0, 0, 0);   // smallest terms first
+                acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[p][0], bf[2], acc[p][q], 0, 0, 0);
+                acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[p][2], bf[0], acc[p][q], 0, 0, 0);
+                acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[p][0], bf[1], acc[p][q], 0, 0, 0);
+                acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[p][1], bf[0], acc[p][q], 0, 0, 0);
+                acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[p][0], bf[0], acc[p][q], 0, 0, 0);
+            }
+        }
+        if (more) stage(buf ^ 1);                         // the other buffer: last read one barrier ago
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int p = 0; p < NI; ++p)
+#pragma unroll
+        for (int q = 0; q < NJ; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = i0 + (wi * NI + p) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const int j = j0 + (wj * NJ + q) * 32 + jj;
+                if (i < a.D && j < a.D) a.out[(size_t)i * a.D + j] = acc[p][q][r];
+            }
+}
+
+template <int TI, int TJ>
+int launch_outer_split(const RhOuterArgs& o, int D, hipStream_t st) {
+    constexpr int lds = 2 * 3 * 16 * ((TI * 2 + 16) + (TJ * 2 + 16));
+    static unsigned long long configured = 0;
+    if (ensure_dynamic_lds(reinterpret_cast<const void*>(rh_outer_split_kernel<TI, TJ>), lds, configured) != PDE_OK) return PDE_E_LAUNCH;
+    hipLaunchKernelGGL((rh_outer_split_kernel<TI, TJ>), dim3((D + TJ - 1) / TJ, (D + TI - 1) / TI), dim3(kRhThreads), lds, st, o);
+    return check_launch();
+}
+
 constexpr size_t strip_lds() {
     // X slabs + the larger of the two W-slab shapes, both double-buffered, + the reduction scratch
     return (size_t)(2 * kRhWaves * 16 * RhSlab<1>::LDA + 2 * (kRhCols * RhSlab<1>::LDA > RhSlab<1>::BK * kRhLdN
@@ -550,6 +698,10 @@ int pde_sym_layer_backward(int32_t B, int32_t D, int32_t act, int32_t training, 
     rc = launch_strip(rh_axpy_strip_kernel<1>, x, D, nblk, st);
     if (rc != PDE_OK) return rc;
     RhOuterArgs o{dP, X, H, g_out, gK, B, D, scale};
+    // three-piece bf16 products on the same 64 x 192 tiles (57 us against 66 at B = 128, D = 3072; 128 x 192 and 128 x 128
+    // tiles: 66 and 63 us); PDE_RH_NO_SPLIT=1 selects the fp32-MFMA kernel
+    static const bool split = getenv("PDE_RH_NO_SPLIT") == nullptr;
+    if (split) return launch_outer_split<kOutTi, kOutTj>(o, D, st);
     hipLaunchKernelGGL(rh_outer_kernel, dim3((D + kOutTj - 1) / kOutTj, (D + kOutTi - 1) / kOutTi), dim3(kRhThreads), 0, st, o);
     return check_launch();
 }
