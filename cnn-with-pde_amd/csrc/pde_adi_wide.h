@@ -37,9 +37,67 @@ struct WideArgs {
 typedef float wide_f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kWideGroup = 8 * 64 * 4;                    // floats of one channel group's slice of the exchange image
 
+// PDE_WIDE_SPLIT (default 1): the operator product on the bf16 matrix cores with every fp32 operand as three bf16 pieces
+// (pde_mix_bf16.hip: six exact piece products per product, fp32-level accuracy, 6/16 of the fp32 MFMA's time); 0: the
+// fp32 MFMA (v_mfma_f32_32x32x2_f32).
+#ifndef PDE_WIDE_SPLIT
+#define PDE_WIDE_SPLIT 1
+#endif
+typedef short wide_v8s __attribute__((ext_vector_type(8)));
+typedef __bf16 wide_v8bf __attribute__((ext_vector_type(8)));
+
 template <int WAVES> constexpr size_t wide_lds_bytes() {
-    return (size_t)(WAVES * kWideGroup + (4 * WAVES / 32) * (4 * WAVES / 8) * 256) * sizeof(float);
+    // exchange image + operator fragments: fp32 [CT][KP][64][4], or three bf16 pieces [3][CT][KS][64][8]
+    return (size_t)WAVES * kWideGroup * sizeof(float) +
+           (PDE_WIDE_SPLIT ? (size_t)3 * (4 * WAVES / 32) * (4 * WAVES / 16) * 64 * 16
+                           : (size_t)(4 * WAVES / 32) * (4 * WAVES / 8) * 256 * sizeof(float));
 }
+
+__device__ __forceinline__ void wide_split3(float x, unsigned short& hi, unsigned short& mid, unsigned short& lo) {
+    hi = f32_to_bf16_hw(x);
+    const float r1 = x - __uint_as_float((unsigned)hi << 16);
+    mid = f32_to_bf16_hw(r1);
+    lo = f32_to_bf16_hw(r1 - __uint_as_float((unsigned)mid << 16));
+}
+// eight fp32 values (two float4) -> three bf16 operand fragments
+__device__ __forceinline__ void wide_split8(const float4& x0, const float4& x1, wide_v8bf (&pc)[3]) {
+    const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    wide_v8s s[3];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        unsigned short a, b, c;
+        wide_split3(v[j], a, b, c);
+        s[0][j] = (short)a; s[1][j] = (short)b; s[2][j] = (short)c;
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) pc[q] = __builtin_bit_cast(wide_v8bf, s[q]);
+}
+// operator fragments for the bf16 MFMA: Af3[piece][ct][ks][lane] = 8 bf16: Op[32 ct + (lane & 31)][16 ks + 8 (lane >> 5) + j]
+template <int WAVES>
+__device__ __forceinline__ void wide_fill_operator3(float* Af, const float* Mg, int tid) {
+    constexpr int C = 4 * WAVES, KS = C / 16, CT = C / 32, FR = CT * KS * 64;
+    uint4* dst = reinterpret_cast<uint4*>(Af);
+    for (int e = tid; e < FR; e += 64 * WAVES) {
+        const int ln = e & 63, ks = (e >> 6) % KS, ct = (e >> 6) / KS;
+        const int i = 32 * ct + (ln & 31), k0 = 16 * ks + 8 * (ln >> 5);
+        unsigned short pc[3][8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wide_split3(Mg[i * C + k0 + j], pc[0][j], pc[1][j], pc[2][j]);
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            dst[q * FR + e] = make_uint4(pc[q][0] | (pc[q][1] << 16), pc[q][2] | (pc[q][3] << 16), pc[q][4] | (pc[q][5] << 16),
+                                         pc[q][6] | (pc[q][7] << 16));
+    }
+}
+#define PDE_WIDE_MFMA6(ACC, A, B)                                                                   \
+    do {                                                                                            \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B[1], ACC, 0, 0, 0);                    \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[2], ACC, 0, 0, 0);                    \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2], B[0], ACC, 0, 0, 0);                    \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[1], ACC, 0, 0, 0);                    \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B[0], ACC, 0, 0, 0);                    \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[0], ACC, 0, 0, 0);                    \
+    } while (0)
 
 // operator fragments: Af[ct][p][lane][q] = M[32 ct + (lane & 31)][8 p + 4 (lane >> 5) + q]   (TRANS: M^T)
 template <int WAVES, bool TRANS>
@@ -84,6 +142,36 @@ __device__ __forceinline__ void wide_mix(float (&v)[4][MM], float* X, const floa
         const int l0 = (C == 64) ? 32 * (w & 1) : 0;
         const float4* Xq = reinterpret_cast<const float4*>(X);
         const float4* Aq = reinterpret_cast<const float4*>(Af);
+#if PDE_WIDE_SPLIT
+        {
+            // contraction group ks = 16 channels = channel groups 4 ks .. 4 ks + 3; lanes 0-31 take the first two (k = 0..7),
+            // lanes 32-63 the other two (k = 8..15): B[k = 8 lh + j][pixel ln] from two float4 of the exchange image
+            constexpr int KS = C / 16, CT = C / 32, FR = CT * KS * 64;
+            const uint4* A3 = reinterpret_cast<const uint4*>(Af);
+            auto afrag = [&](int ct, int ks, wide_v8bf (&pc)[3]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) pc[q] = __builtin_bit_cast(wide_v8bf, A3[q * FR + (ct * KS + ks) * 64 + lane]);
+            };
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                wide_v8bf b0[3];
+                wide_split8(Xq[((4 * ks + 2 * lh) * 8 + kk0) * 64 + l0 + ln], Xq[((4 * ks + 2 * lh + 1) * 8 + kk0) * 64 + l0 + ln], b0);
+                if constexpr (C == 64) {
+                    wide_v8bf a0[3], a1[3];
+                    afrag(0, ks, a0);
+                    afrag(1, ks, a1);
+                    PDE_WIDE_MFMA6(acc[0], a0, b0);
+                    PDE_WIDE_MFMA6(acc[1], a1, b0);
+                } else {
+                    wide_v8bf b1[3], a0[3];
+                    wide_split8(Xq[((4 * ks + 2 * lh) * 8 + kk0) * 64 + 32 + ln], Xq[((4 * ks + 2 * lh + 1) * 8 + kk0) * 64 + 32 + ln], b1);
+                    afrag(0, ks, a0);
+                    PDE_WIDE_MFMA6(acc[0], a0, b0);
+                    PDE_WIDE_MFMA6(acc[1], a0, b1);
+                }
+            }
+        }
+#else
 #pragma unroll
         for (int p = 0; p < KP; ++p) {
             const float4 b0 = Xq[((2 * p + lh) * 8 + kk0) * 64 + l0 + ln];
@@ -110,6 +198,7 @@ __device__ __forceinline__ void wide_mix(float (&v)[4][MM], float* X, const floa
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b1.w, acc[1], 0, 0, 0);
             }
         }
+#endif
         // products back in place: D row = (r & 3) + 8 (r >> 2) + 4 lh -> channel group 8 ct + 2 (r >> 2) + lh, member r & 3
         {
             float4* Xw = reinterpret_cast<float4*>(X);
@@ -165,7 +254,8 @@ __global__ __launch_bounds__(64 * WAVES) void adi_wide_fwd_kernel(WideArgs a) {
     float* X = smem;
     float* T = X + (size_t)w * kWideGroup;
     float* Af = smem + (size_t)WAVES * kWideGroup;
-    wide_fill_operator<WAVES, false>(Af, a.M, tid);
+    if constexpr (PDE_WIDE_SPLIT) wide_fill_operator3<WAVES>(Af, a.M, tid);
+    else wide_fill_operator<WAVES, false>(Af, a.M, tid);
     for (int e = lane; e < kWideGroup; e += 64) T[e] = 0.f;             // idle lanes (N < 32) never meet uninitialised LDS
     const float* u = static_cast<const float*>(a.u);
     float* st = static_cast<float*>(a.states);
