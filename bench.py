@@ -510,8 +510,9 @@ def main():
         if rank == 0:
             out["secondary"] = {"config": "same workload with the C x C channel mixing before every step "
                                           "(cifar10.py:91): one factorisation, the forward in ONE launch (a workgroup owns all 64 channels of a "
-                                          "sample, fp32-MFMA mixing through LDS); backward per step: 3-sweep adjoint launch + fused "
-                                          "mixing-gradient kernel, gradients accumulated on the device",
+                                          "sample, the operator through LDS as three-piece bf16 products on the bf16 MFMA, fp32-accurate); "
+                                          "backward per step: 3-sweep adjoint launch + fused mixing-gradient kernel (three-piece bf16 "
+                                          "products as well), gradients accumulated on the device",
                                 "value": B * world * k2 / dt2 / 1e6, "unit": "Msamples/s",
                                 "ms_per_step": dt2 / k2 * 1e3}
         del layer2
