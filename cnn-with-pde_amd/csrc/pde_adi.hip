@@ -43,6 +43,7 @@
 #include "pde_adi_wide.h"
 #include "pde_adi_launch.h"
 #include "pde_adi_gen.h"
+#include "pde_adi_asm.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -753,9 +754,28 @@ int launch_bwd_sweeps(const PdeAdiDesc* d, const void* gy, const void* y, const 
         rc = dispatch_fwd(d, kSplitAny, fa, fa.G * d->C, lds_f, st, false);
         if (rc != PDE_OK) return rc;
     }
+    // N = 32, fp32 tensors, Strang steps, no checkpoints: the fast body runs as the hand-scheduled assembly kernel
+    // (gen_adi_bwd_asm.py: 168 VGPRs, three waves per SIMD), the masked body as a launch of its own over the same groups
+    const int split = split_of(d);
+    const int nw = asm_bwd_waves();
+    if (nw && d->N == 32 && d->io_dtype == PDE_IO_F32 && split == kSplitStrang && !nck && d->num_sweeps >= 3) {
+        AsmBwdArgs aa{};
+        aa.gy = gy; aa.y = y; aa.gu = gu; aa.coef = coef; aa.part = part; aa.tab = tab; aa.varying = varying;
+        aa.B = d->B; aa.C = d->C; aa.S = d->num_sweeps; aa.G = G;
+        aa.gu_scale = sa.gu_scale; aa.acc_part = accumulate;
+        aa.K = d->num_sweeps / 3;
+        aa.nchunk = (d->B + asm_bwd_planes(nw) - 1) / asm_bwd_planes(nw);
+        sa.only_masked = 1;
+        return timed_launch([&]() -> int {
+            const int rc2 = asm_bwd_launch(nw, aa, sa.xcd_map, st);
+            if (rc2 != PDE_OK) return rc2;
+            if (env_int("PDE_ASM_NO_MASKED", 0)) return PDE_OK;          // diagnostics only
+            return adi_launch_bwd_32(d->io_dtype, split, &sa, G * d->C, st);
+        }, st, false, true);
+    }
     // one launch, two halves of the grid: fast variant | masked variant; a workgroup leaves at once unless
     // its channel belongs to its variant (decided on the device by the factor kernel, no host round trip)
-    return dispatch_bwd(d, split_of(d), sa, 2 * G * d->C, st);
+    return dispatch_bwd(d, split, sa, 2 * G * d->C, st);
 }
 
 // parameter gradients from the partial sums; `d` is the WHOLE schedule the sums were taken over

@@ -71,6 +71,7 @@ struct SweepArgs {
     int pair_x;             // Strang schedules: the last x sweep of a step and the first of the next have the SAME record
                             // (same time, same increment): its rows are loaded from LDS once for the two sweeps
     void* dbg;              // diagnostic builds only
+    int only_masked;        // bwd: the grid is C*G blocks of the MASKED body alone (the fast body ran as the assembly kernel)
 };
 
 // The sweep table and the channel flags are written by an earlier kernel and only read here.
@@ -1204,6 +1205,12 @@ __device__ __forceinline__ void adi_bwd_body(const SweepArgs& a, int blk) {
 template <int N, int J, typename IO, int SPLIT>
 __global__ __launch_bounds__(kThreads, PDE_BWD_MINW) void adi_bwd_kernel(SweepArgs a) {
     const int nb = a.C * a.G;
+    if (a.only_masked) {
+#ifndef PDE_BWD_NO_MASKED
+        adi_bwd_body<N, 1, IO, true, kSplitAny>(a, (int)blockIdx.x);
+#endif
+        return;
+    }
     if ((int)blockIdx.x < nb) adi_bwd_body<N, J, IO, false, SPLIT>(a, (int)blockIdx.x);
 #ifndef PDE_BWD_NO_MASKED        // diagnostic builds: the fast body alone (its own register allocation)
     else adi_bwd_body<N, 1, IO, true, kSplitAny>(a, (int)blockIdx.x - nb);

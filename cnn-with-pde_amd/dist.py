@@ -64,6 +64,7 @@ class GradBucket:
         self._pending_div = None
         self._hooks = []
         self._arrived = 0
+        self._launched = False          # a collective has been started (by start() or by the hooks) and not finished
         if grads_as_views:
             self.install_views()
 
@@ -101,6 +102,11 @@ class GradBucket:
     # ---- the collective --------------------------------------------------------------------------------------
     def start(self, average: bool = True, group=None) -> None:
         """Gather (unless the gradients are views) and launch the all-reduce without waiting for it."""
+        if self._launched:
+            raise RuntimeError("GradBucket.start(): the previous collective has not been finished — call finish() once per "
+                               "backward (gradient accumulation over several backwards needs detach_hooks() + allreduce())")
+        self._arrived = 0
+        self._launched = True
         self._scatter = not self._is_viewed()
         if self._scatter:
             missing = [i for i, p in enumerate(self.params) if p.grad is None]
@@ -130,7 +136,18 @@ class GradBucket:
                 self._work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
 
     def finish(self) -> None:
-        """Wait for the collective launched by ``start`` (or by the hooks) and put the result where ``.grad`` is."""
+        """Wait for the collective launched by ``start`` (or by the hooks) and put the result where ``.grad`` is.
+
+        With hooks attached, a backward in which some parameter of the bucket received no gradient never launches the
+        collective: that is an error here (in a multi-rank job the ranks' parameters would silently drift apart)."""
+        if self._hooks and not self._launched:
+            arrived, self._arrived = self._arrived, 0
+            multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+            if multi or arrived:
+                raise RuntimeError(f"GradBucket.finish(): no all-reduce was launched by the backward hooks "
+                                   f"({arrived} of {len(self.params)} gradients arrived since the last finish()); every "
+                                   f"parameter of the bucket must receive a gradient in every backward")
+        self._launched = False
         if self._work is not None:
             self._work.wait()
             self._work = None
@@ -162,9 +179,12 @@ class GradBucket:
         n = len(self.params)
 
         def hook(_p):
+            if self._launched:
+                raise RuntimeError("GradBucket: a gradient arrived while the all-reduce of the previous backward is still "
+                                   "pending — call finish() after every backward")
             self._arrived += 1
             if self._arrived == n:
-                self.start(average, group)
+                self.start(average, group)          # resets the arrival counter
         self._hooks = [p.register_post_accumulate_grad_hook(hook) for p in self.params]
 
     def detach_hooks(self) -> None:
@@ -172,3 +192,5 @@ class GradBucket:
             h.remove()
         self._hooks = []
         self._arrived = 0
+        if self._work is None:
+            self._launched = False

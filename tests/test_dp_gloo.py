@@ -19,12 +19,27 @@ def _free_port():
     return p
 
 
+PORT_TAKEN = 97          # exit code of a rank whose rendezvous could not bind / connect
+
+
+def _init(rank, world, port):
+    """Rendezvous on 127.0.0.1.  The port was picked by binding port 0 and releasing it, which another process can win in
+    between: a rank that cannot rendezvous exits with PORT_TAKEN, the only failure the launcher retries."""
+    import sys
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=60))
+    except Exception as e:        # noqa: BLE001  (address in use, connection refused, rendezvous timeout)
+        print("rendezvous failed:", repr(e), file=sys.stderr, flush=True)
+        os._exit(PORT_TAKEN)
+
+
 def _launch(world, worker, timeout):
-    """Start `world` ranks on 127.0.0.1 and return what rank 0 puts on the queue.  The rendezvous port is picked by binding
-    port 0 and releasing it, which another process can win in between: one more attempt on a fresh port in that case."""
+    """Start `world` ranks on 127.0.0.1 and return what rank 0 puts on the queue.  Retried once ONLY when the rendezvous
+    port was taken (every failing rank exited with PORT_TAKEN before any work); a rank that crashes or returns non-zero
+    for any other reason fails the test at once."""
     import queue
     ctx = mp.get_context("spawn")
-    last = None
     for attempt in range(2):
         q = ctx.Queue()
         port = _free_port()
@@ -33,24 +48,27 @@ def _launch(world, worker, timeout):
             p.start()
         try:
             got = q.get(timeout=timeout)
-        except queue.Empty as e:
-            got, last = None, e
+        except queue.Empty:
+            got = None
         for p in procs:
             p.join(timeout=60)
             if p.is_alive():
                 p.terminate()
-        if got is not None and all(p.exitcode == 0 for p in procs):
+                p.join(timeout=10)
+        codes = [p.exitcode for p in procs]
+        if got is not None and all(c == 0 for c in codes):
             return got
-        last = last or RuntimeError(f"rank exit codes {[p.exitcode for p in procs]}")
-    raise last
+        rendezvous_only = any(c == PORT_TAKEN for c in codes) and all(c in (0, PORT_TAKEN, None, -15) for c in codes)
+        if not (rendezvous_only and attempt == 0):
+            raise RuntimeError(f"rank exit codes {codes} (attempt {attempt}); result received: {got is not None}")
+    raise AssertionError("unreachable")
 
 
 def _worker(rank, world, port, q):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path[:0] = [root, os.path.join(root, "tests")]
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _init(rank, world, port)
     torch.set_num_threads(1)
     from oracle import pde_oracle as O
     import cnn_with_pde_amd as P
@@ -89,8 +107,7 @@ def _worker4(rank, world, port, q):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path[:0] = [root, os.path.join(root, "tests")]
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _init(rank, world, port)
     torch.set_num_threads(1)
     from oracle import pde_oracle as O
     import cnn_with_pde_amd as P
@@ -132,3 +149,61 @@ def test_four_ranks_ragged_batch_sum_semantics_views_and_hooks():
     for step in got:
         for k, v in params.items():
             assert torch.allclose(step[k], v.grad, rtol=1e-5, atol=1e-6), k
+
+
+def _worker_missing(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "tests")]
+    _init(rank, world, port)
+    torch.set_num_threads(1)
+    import cnn_with_pde_amd as P
+    a = torch.nn.Parameter(torch.ones(4))
+    b = torch.nn.Parameter(torch.ones(3))
+    out = {}
+    bucket = P.GradBucket([a, b], grads_as_views=True)
+    bucket.attach_hooks(average=False)
+    # (1) a backward in which one parameter of the bucket gets no gradient: finish() must refuse, not return silently
+    bucket.zero()
+    (a * (rank + 1)).sum().backward()
+    try:
+        bucket.finish()
+        out["missing"] = "silent"
+    except RuntimeError as e:
+        out["missing"] = "raised" if "1 of 2" in str(e) else repr(e)
+    # (2) the bucket works again afterwards, and the counter starts from zero
+    bucket.zero()
+    ((a * (rank + 1)).sum() + (b * 2.0).sum()).backward()
+    bucket.finish()
+    out["after"] = (a.grad.clone(), b.grad.clone())
+    # (3) a second backward without finish() in between: the hook refuses (the collective is still pending)
+    bucket.zero()
+    ((a * 1.0).sum() + (b * 1.0).sum()).backward()
+    try:
+        ((a * 1.0).sum() + (b * 1.0).sum()).backward()
+        out["double"] = "silent"
+    except RuntimeError as e:
+        out["double"] = "raised" if "finish()" in str(e) else repr(e)
+    bucket.finish()
+    # (4) and a plain start() twice is refused as well
+    bucket.detach_hooks()
+    bucket.start(average=False)
+    try:
+        bucket.start(average=False)
+        out["restart"] = "silent"
+    except RuntimeError:
+        out["restart"] = "raised"
+    bucket.finish()
+    if rank == 0:
+        q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_hooks_refuse_missing_gradient_and_missed_finish():
+    got = _launch(2, _worker_missing, 120)
+    assert got["missing"] == "raised", got
+    assert got["double"] == "raised", got
+    assert got["restart"] == "raised", got
+    ga, gb = got["after"]
+    assert torch.equal(ga, torch.full((4,), 3.0)) and torch.equal(gb, torch.full((3,), 4.0)), got
