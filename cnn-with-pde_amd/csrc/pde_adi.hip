@@ -762,7 +762,7 @@ int launch_bwd_sweeps(const PdeAdiDesc* d, const void* gy, const void* y, const 
         AsmBwdArgs aa{};
         aa.gy = gy; aa.y = y; aa.gu = gu; aa.coef = coef; aa.part = part; aa.tab = tab; aa.varying = varying;
         aa.B = d->B; aa.C = d->C; aa.S = d->num_sweeps; aa.G = G;
-        aa.gu_scale = sa.gu_scale; aa.acc_part = accumulate;
+        aa.gu_scale = sa.gu_scale; aa.acc_part = (accumulate ? 1 : 0) | (sa.pair_x ? 2 : 0);
         aa.K = d->num_sweeps / 3;
         aa.nchunk = (d->B + asm_bwd_planes(nw) - 1) / asm_bwd_planes(nw);
         sa.only_masked = 1;

@@ -16,7 +16,8 @@ struct AsmBwdArgs {
     const int* varying;     // [C]: channels with a time-dependent clamp mask are skipped (the masked HIP body owns them)
     int B, C, S, G;
     float gu_scale;         // (1+eps)^-S
-    int acc_part;           // add to what `part` holds
+    int acc_part;           // flags: bit 0 = add to what `part` holds, bit 1 = the schedule's twin x sweeps (last of a step,
+                            // first of the next) have identical records (strang_pairs_identical)
     int cz_mul;             // channel = blockIdx.x + cz_mul * blockIdx.z
     int K;                  // time steps = S / 3
     int nchunk;             // ceil(B / planes per workgroup pass)
