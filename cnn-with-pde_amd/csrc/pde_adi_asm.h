@@ -5,7 +5,7 @@
 
 namespace pde {
 
-// kernel-argument block of adi_bwd_asm_n32_w<NW> (96 bytes; the kernel reads it with two scalar loads)
+// kernel-argument block of adi_bwd_asm_n32_w<NW> (104 bytes; the kernel reads it with two scalar loads)
 struct AsmBwdArgs {
     const void* gy;         // upstream gradient (B,C,32,32) fp32
     const void* y;          // layer output
@@ -21,9 +21,10 @@ struct AsmBwdArgs {
     int cz_mul;             // channel = blockIdx.x + cz_mul * blockIdx.z
     int K;                  // time steps = S / 3
     int nchunk;             // ceil(B / planes per workgroup pass)
-    int pad;
+    int pad;                // diagnostic stop stage (0 in production)
+    void* dbg;              // diagnostic builds: cycle stamps [wave][16] (null otherwise)
 };
-static_assert(sizeof(AsmBwdArgs) == 96, "kernel-argument layout");
+static_assert(sizeof(AsmBwdArgs) == 104, "kernel-argument layout");
 
 // waves per workgroup of the variant that will run (0: none available / disabled by PDE_ASM_BWD=0)
 int asm_bwd_waves();
