@@ -758,7 +758,8 @@ int launch_bwd_sweeps(const PdeAdiDesc* d, const void* gy, const void* y, const 
     // (gen_adi_bwd_asm.py: 168 VGPRs, three waves per SIMD), the masked body as a launch of its own over the same groups
     const int split = split_of(d);
     const int nw = asm_bwd_waves();
-    if (nw && d->N == 32 && d->io_dtype == PDE_IO_F32 && split == kSplitStrang && !nck && d->num_sweeps >= 3) {
+    // (one-step launches — the layers with a channel operator — stay with the HIP kernel, whose records are resident)
+    if (nw && d->N == 32 && d->io_dtype == PDE_IO_F32 && split == kSplitStrang && !nck && d->num_sweeps >= 6) {
         AsmBwdArgs aa{};
         aa.gy = gy; aa.y = y; aa.gu = gu; aa.coef = coef; aa.part = part; aa.tab = tab; aa.varying = varying;
         aa.B = d->B; aa.C = d->C; aa.S = d->num_sweeps; aa.G = G;
