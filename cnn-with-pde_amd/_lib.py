@@ -59,6 +59,7 @@ _D = C.POINTER(PdeAdiDesc)
 # name -> (restype, argtypes): must list every symbol include/pdecnn.h declares
 SIGNATURES = {
     "pde_adi_line_length_path": (C.c_int, [_i32]),
+    "pde_adi_backward_kernel": (C.c_int, [C.POINTER(PdeAdiDesc), _i32]),
     "pde_adi_forward_workspace_bytes": (_sz, [_D]),
     "pde_adi_backward_workspace_bytes": (_sz, [_D, _i32]),
     "pde_adi_forward": (C.c_int, [_D, _vp, _vp, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _vp, _sz, _vp]),

@@ -724,6 +724,13 @@ int ckpt_plan(const PdeAdiDesc* d, const uint64_t ckpt_mask[2], const void* u, i
     return PDE_OK;
 }
 
+// the hand-scheduled assembly kernel serves N = 32, fp32 tensors, Strang schedules of two or more steps without checkpoints
+// (one-step launches — the layers with a channel operator — stay with the HIP kernel, whose records are resident)
+bool asm_bwd_eligible(const PdeAdiDesc* d, int nck) {
+    return asm_bwd_waves() && d->N == 32 && d->io_dtype == PDE_IO_F32 && split_of(d) == kSplitStrang && !nck &&
+           d->num_sweeps >= 6;
+}
+
 // backward sweeps of `d`: optional checkpoint pre-pass, then the adjoint launch.  Partial gradient sums
 // go to `part` ([G][C][4][image]); with `accumulate` they are ADDED to what is there (per-step launches
 // of one layer call: every workgroup owns its slots, so this is race-free and order-independent).
@@ -758,8 +765,7 @@ int launch_bwd_sweeps(const PdeAdiDesc* d, const void* gy, const void* y, const 
     // (gen_adi_bwd_asm.py: 168 VGPRs, three waves per SIMD), the masked body as a launch of its own over the same groups
     const int split = split_of(d);
     const int nw = asm_bwd_waves();
-    // (one-step launches — the layers with a channel operator — stay with the HIP kernel, whose records are resident)
-    if (nw && d->N == 32 && d->io_dtype == PDE_IO_F32 && split == kSplitStrang && !nck && d->num_sweeps >= 6) {
+    if (asm_bwd_eligible(d, nck)) {
         AsmBwdArgs aa{};
         aa.gy = gy; aa.y = y; aa.gu = gu; aa.coef = coef; aa.part = part; aa.tab = tab; aa.varying = varying;
         aa.B = d->B; aa.C = d->C; aa.S = d->num_sweeps; aa.G = G;
@@ -852,6 +858,12 @@ using namespace pde;
 extern "C" {
 
 int pde_adi_line_length_path(int32_t N) { return fused_n(N) ? 1 : (gen_n_ok(N) ? 2 : 0); }
+
+int pde_adi_backward_kernel(const PdeAdiDesc* d, int32_t num_checkpoints) {
+    if (check_desc(d, true) != PDE_OK) return PDE_E_BADARG;
+    if (!fused_n(d->N)) return 2;
+    return asm_bwd_eligible(d, num_checkpoints) ? 1 : 0;
+}
 
 size_t pde_adi_forward_workspace_bytes(const PdeAdiDesc* d) {
     if (check_desc(d, true) != PDE_OK) return 0;

@@ -75,6 +75,13 @@ typedef struct PdeAdiDesc {
  * 0 = unsupported. */
 int pde_adi_line_length_path(int32_t N);
 
+/* Which kernel pde_adi_backward runs for this schedule's unmasked channels: 0 = the HIP kernel (adi_bwd_kernel), 1 = the
+ * hand-scheduled gfx950 assembly kernel (csrc/gen_adi_bwd_asm.py: N = 32, fp32 tensors, Strang steps — mnist_test.py:55-63,
+ * cifar10.py:84-110 — two or more of them, no checkpoints), 2 = the any-size kernels.  Same arithmetic either way: the
+ * adjoint of the time loop and the batch sums of the coefficient gradients; PDE_ASM_BWD=0 in the
+ * environment keeps the library on 0. */
+int pde_adi_backward_kernel(const PdeAdiDesc* d, int32_t num_checkpoints);
+
 /* Bytes of scratch the forward/backward calls need (256-byte aligned base expected). */
 size_t pde_adi_forward_workspace_bytes(const PdeAdiDesc* d);
 size_t pde_adi_backward_workspace_bytes(const PdeAdiDesc* d, int32_t num_checkpoints);
