@@ -157,6 +157,20 @@ def cpu_baseline(C, N, steps, sample_B):
     return out
 
 
+def pmc_extra(work):
+    """HBM bytes per forward+backward of a workload from the committed counter passes (FETCH_SIZE doubled + WRITE_SIZE over
+    ALL this library's launches of a step: profiles/pmc_traffic.json, tools/pmc_round.sh), or None"""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.isfile(path):
+        return None
+    with open(path) as f:
+        pj = json.load(f)
+    if work + "_bytes_per_step" not in pj:
+        return None
+    return {"hbm_bytes_per_step": pj[work + "_bytes_per_step"], "taken_at_commit": pj.get("commit"),
+            "largest_kernels": pj.get(work + "_kernels")}
+
+
 def config_legs(dev, rank, world, dist_on, quick):
     """The other BASELINE.json configurations, per-GPU batch fixed (weak scaling), each timed like
     the headline: warm-up, K steps between barrier+synchronize, max over ranks, gradients all-reduced when N > 1.
@@ -435,13 +449,25 @@ def main():
             graph_ms = "capture failed: %s" % (str(e)[:120],)
 
     out = None
+    # which kernel the backward of this schedule is (the hand-scheduled assembly kernel since round 4: include/pdecnn.h)
+    bwd_kernel = "adi_bwd_kernel"
+    try:
+        import ctypes
+        import cnn_with_pde_amd.functional as F_
+        import cnn_with_pde_amd._lib as L_
+        sw_ = [s_ for st_ in P.adi_schedule(layer.dt, layer.dx, layer.dy, steps) for s_ in st_]
+        d_ = F_._build_desc(B, C, N, L_.PDE_IO_F32, sw_, False, 10.0, 1e-6)
+        if L_.load().pde_adi_backward_kernel(ctypes.byref(d_), 0) == 1:
+            bwd_kernel = "adi_bwd_asm_n32_w" + os.environ.get("PDE_ASM_VARIANT", "8b")
+    except Exception:
+        pass
     if rank == 0:
         pmc, valu, pmc_src = None, None, None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.isfile(pmc_path) and (B, C, N, steps) == (512, 64, 32, 10):     # counters were taken on this workload
             with open(pmc_path) as f:
                 pj = json.load(f)
-            pmc = pj.get("adi_bwd_kernel_bytes_per_launch")
+            pmc = pj.get("adi_bwd_kernel_bytes_per_launch") if pj.get("bwd_kernel", "adi_bwd_kernel").startswith(bwd_kernel[:11]) else None
             valu = pj.get("sq_insts_valu_per_launch")
             pmc_src = {"file": "profiles/pmc_traffic.json", "taken_at_commit": pj.get("commit"), "passes": pj.get("source")}
         ach = elems * BYTES_PER_ELEM["bwd"] / (bwd_ms * 1e-3) / 1e9
@@ -460,7 +486,7 @@ def main():
                 "value": (B * world / (graph_ms * 1e-3) / 1e6) if isinstance(graph_ms, float) else None, "unit": "Msamples/s",
                 "note": "the same forward+backward captured once (cnn_with_pde_amd.graphs.GraphedStep, checkpoint plan "
                         "frozen) and replayed: no Python/autograd/ctypes per step; `value` above is the eager path"},
-            "roofline": {"bound": "hbm", "kernel": "adi_bwd_kernel", "achieved": ach, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": bwd_kernel, "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc, "traffic_source": pmc_src,
                          "copy_ceiling_measured": copy_gbs,
                          "algorithmic_bytes_per_launch": elems * BYTES_PER_ELEM["bwd"], "avg_launch_ms": bwd_ms},
@@ -514,7 +540,11 @@ def main():
                                           "backward per step: 3-sweep adjoint launch + fused mixing-gradient kernel (three-piece bf16 "
                                           "products as well), gradients accumulated on the device",
                                 "value": B * world * k2 / dt2 / 1e6, "unit": "Msamples/s",
-                                "ms_per_step": dt2 / k2 * 1e3}
+                                "ms_per_step": dt2 / k2 * 1e3,
+                                "algorithmic_bytes_per_step": B * C * N * N * BYTES_PER_ELEM["step"]}
+            tr = pmc_extra("secondary")
+            if tr and (B, C, N, steps) == (512, 64, 32, 10):
+                out["secondary"]["traffic"] = tr
         del layer2
 
     if not a.no_configs:
@@ -522,6 +552,9 @@ def main():
         torch.cuda.empty_cache()
         legs = config_legs(dev, rank, world, dist_on, quick=a.steps < 20)
         if rank == 0:
+            tr = pmc_extra("cfg4")
+            if tr and isinstance(legs.get("cfg4_bf16"), dict):
+                legs["cfg4_bf16"]["traffic"] = tr
             out["configs"] = legs
 
     if rank == 0:
