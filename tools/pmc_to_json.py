@@ -51,6 +51,11 @@ for k, key in ((BWD, "adi_bwd_kernel"), ("adi_fwd_kernel", "adi_fwd_kernel")):
         j[key + "_fetch_size_kb"], j[key + "_write_size_kb"] = f, w
 
 
+def short(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "").replace("pde::", "")
+    return name.split("(")[0][:80]
+
+
 def per_step(work, steps):
     """HBM bytes of ALL this library's launches of one forward+backward of a workload, and the per-kernel split"""
     fr, wr = P[work + "_fetch"], P[work + "_write"]
@@ -59,11 +64,11 @@ def per_step(work, steps):
     tot = collections.defaultdict(lambda: [0.0, 0.0, 0])
     for r in fr:
         if r["Counter_Name"] == "FETCH_SIZE":
-            t = tot[r["Kernel_Name"].split("(")[0][:90]]
+            t = tot[short(r["Kernel_Name"])]
             t[0] += float(r["Counter_Value"]); t[2] += 1
     for r in wr:
         if r["Counter_Name"] == "WRITE_SIZE":
-            tot[r["Kernel_Name"].split("(")[0][:90]][1] += float(r["Counter_Value"])
+            tot[short(r["Kernel_Name"])][1] += float(r["Counter_Value"])
     j[work + "_bytes_per_step"] = int(sum((2 * f + w) for f, w, _ in tot.values()) * 1024 / steps)
     j[work + "_kernels"] = {k: {"launches_per_step": n / steps, "mb_per_launch": round((2 * f + w) * 1024 / n / 1e6, 2)}
                             for k, (f, w, n) in sorted(tot.items(), key=lambda kv: -(2 * kv[1][0] + kv[1][1]))[:12]}
