@@ -270,10 +270,16 @@ def config_legs(dev, rank, world, dist_on, quick):
             torch.cuda.synchronize()
             return (time.perf_counter() - t0) / reps * 1e3
         ms_f, ms_t = sl_ms(True, 2 * k), sl_ms(False, 2 * k)
+        # the reference's own training batch is 64 (cifar_2version.py:476)
+        xs = torch.randn(64, 3, 32, 32, generator=g).to(dev).requires_grad_(True)
+        gs = torch.randn(64, 3, 32, 32, generator=g).to(dev)
+        ms_f64, ms_t64 = sl_ms(True, 2 * k), sl_ms(False, 2 * k)
         flop = 6 * 2.0 * 128 * 3072 * 3072
         if rank == 0:
-            legs["rh_symmetric"] = {"workload": "cifar_2version.SymmetricLayer(3, 32): -act(BN(Y K^T)) K, K 3072 x 3072 fp32, batch 128, "
-                                                "training mode, forward + backward (cifar_2version.py:190-220)",
+            legs["rh_symmetric"] = {"workload": "cifar_2version.SymmetricLayer(3, 32): -act(BN(Y K^T)) K, K 3072 x 3072 fp32, batch 128 "
+                                                "(twice the reference's training batch of 64, cifar_2version.py:476: `batch_64` beside "
+                                                "it), training mode, forward + backward (cifar_2version.py:190-220)",
+                                    "batch_64": {"ms_per_step": ms_f64, "ms_per_step_plain_torch_rocblas": ms_t64},
                                     "ms_per_step": ms_f, "ms_per_step_plain_torch_rocblas": ms_t, "value": 128 / ms_f / 1e3,
                                     "unit": "Msamples/s", "dtype": "f32",
                                     "roofline": {"bound": "mfma", "achieved": flop / (ms_f * 1e-3) / 1e12, "peak": 157.3,

@@ -19,6 +19,9 @@
 // Boundary: plain pointers, caller-owned buffers, asynchronous on the given stream (include/pdecnn.h).
 #include "pde_common.h"
 
+#include <map>
+#include <mutex>
+
 #include <cstdlib>
 
 namespace pde {
@@ -627,9 +630,19 @@ constexpr size_t strip_lds() {
                     ? kRhCols * RhSlab<1>::LDA : RhSlab<1>::BK * kRhLdN) + kRhWaves * 64) * sizeof(float);
 }
 constexpr int kRhRows = kRhWaves * 16;                    // batch rows of one strip workgroup (128)
+// The "dynamic LDS limit set on device d" bits are kept per KERNEL ADDRESS: two kernels with the same signature
+// (rh_axpy_strip_kernel<1> and rh_nt_strip_kernel<1> both take RhAxpyArgs) are the same template instantiation of this
+// function, so a function-local static would be shared and only the first of them would ever get its attribute.
 template <typename ARGS, typename KERN>
 int launch_strip(KERN kern, const ARGS& a, int D, int row_blocks, hipStream_t st) {
-    static unsigned long long configured = 0;             // one per kernel instantiation
+    static std::mutex mu;
+    static std::map<const void*, unsigned long long> done;
+    unsigned long long* bits;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        bits = &done[reinterpret_cast<const void*>(kern)];    // (std::map nodes do not move)
+    }
+    unsigned long long& configured = *bits;
     if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)strip_lds(), configured) != PDE_OK) return PDE_E_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(D / kRhCols, row_blocks), dim3(kRhStripThreads), strip_lds(), st, a);
     return check_launch();

@@ -225,15 +225,22 @@ def _kmax_channel(n: int):
                 e.owner = None
                 ring["entries"].append(e)
             _kmax_rings[dev] = ring
-        e = ring["entries"][ring["next"]]
-        if e.owner is not None and e.owner() is not None:  # still held by a call whose backward is outstanding
+        # the first free entry from `next` on: one long-lived ticket (an output kept without a backward, activation
+        # checkpointing) must not make every later call allocate pinned memory and an event of its own
+        e = None
+        for off in range(KMAX_RING):
+            i = (ring["next"] + off) % KMAX_RING
+            c = ring["entries"][i]
+            if c.owner is None or c.owner() is None:
+                e = c
+                ring["next"] = (i + 1) % KMAX_RING
+                break
+        if e is None:                                      # every entry is held by a call whose backward is outstanding
             e = _KmaxEntry()
             e.host = torch.empty(L.PDE_MAX_SWEEPS * 4, dtype=torch.float32, pin_memory=True)
             e.event = torch.cuda.Event()
             e.event.record()
             e.gen = 0
-        else:
-            ring["next"] = (ring["next"] + 1) % KMAX_RING
         e.gen += 1
         t = _KmaxTicket(e, n)
         e.owner = weakref.ref(t)
@@ -285,6 +292,36 @@ class _KmaxTicket:
         """Values once the copy has landed (waits for the factorisation kernel only)."""
         _wait_event(self.event)
         return self.host.tolist()
+
+
+class _KmaxConcat:
+    """The maxima of several calls in call order (a layer composed from per-step calls): ``host`` / ``event`` like a ticket."""
+    __slots__ = ("parts",)
+
+    def __init__(self, parts):
+        self.parts = list(parts)
+
+    class _Ev:
+        def __init__(self, evs):
+            self.evs = evs
+
+        def query(self):
+            return all(e.query() for e in self.evs)
+
+        def synchronize(self):
+            for e in self.evs:
+                e.synchronize()
+
+    @property
+    def event(self):
+        return _KmaxConcat._Ev([p.event for p in self.parts])
+
+    @property
+    def host(self):
+        return torch.cat([p.host for p in self.parts])
+
+    def wait(self):
+        return [v for p in self.parts for v in p.wait()]
 
 
 class _AdiFn(torch.autograd.Function):
@@ -717,13 +754,16 @@ def adi_diffuse_mixed(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coef
         # a line length without fused kernels (pde_adi_line_length_path: any size up to PDE_MAX_N_GENERIC): the per-step
         # entry points do not exist there; compose the layer from its own pieces — the channel operator and the sweeps of
         # one step per call, chained by autograd (the step-local checkpoint mask applies to every step unchanged)
+        tickets = [] if kmax_sink is not None else None
         for st in steps:
             if mode == "pre":
                 u = channel_mix(u, M)
             u = adi_diffuse(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff, st, smooth3=smooth3,
-                            clamp_max=clamp_max, eps=eps, checkpoints=checkpoints)
+                            clamp_max=clamp_max, eps=eps, checkpoints=checkpoints, kmax_sink=tickets)
             if mode == "post":
                 u = channel_mix(u, M)
+        if tickets and len(tickets) == len(steps):           # the whole layer's maxima, step after step (lagged plans)
+            kmax_sink.append(_KmaxConcat(tickets))
         return u
     return _AdiMixedFn.apply(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff, M, steps, mode, bool(smooth3),
                              clamp_max, float(eps), checkpoints, kmax_sink)
@@ -916,6 +956,9 @@ class _SymLayerFn(torch.autograd.Function):
         return gX, gK, gg, gb, (g if has_base else None), None, None, None, None, None, None, None
 
 
+SYM_LAYER_MAX_ROWS = 128      # one strip workgroup owns all rows of its 16 features up to here (the reference trains at 64)
+
+
 def sym_layer_supported(X, bn) -> bool:
     """Whether ``sym_layer`` takes this input: an fp32 CUDA batch whose feature count is a multiple of
     64, outside autocast, and a BatchNorm1d with affine parameters and a fixed momentum."""
@@ -926,7 +969,13 @@ def sym_layer_supported(X, bn) -> bool:
         return False
     if not bn.training and bn.running_mean is None:
         pass                                              # eval without running statistics = batch statistics: supported
-    return bool(L.load().pde_sym_layer_supported(X.shape[0], D))
+    B = X.shape[0]
+    # Policy, not capability (``sym_layer`` itself takes any batch): above SYM_LAYER_MAX_ROWS rows the row-block kernels
+    # are 1.6-1.9x behind rocBLAS, so the module-level callers keep plain torch there; a training-mode
+    # batch of one row is refused by torch.nn.BatchNorm1d ("Expected more than 1 value per channel") and must stay so.
+    if B > SYM_LAYER_MAX_ROWS or (B == 1 and (bn.training or bn.running_mean is None)):
+        return False
+    return bool(L.load().pde_sym_layer_supported(B, D))
 
 
 def sym_layer(X, K, bn, activation: str = "relu", base=None, scale: float = -1.0):

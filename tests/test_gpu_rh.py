@@ -31,11 +31,17 @@ def _module(g):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", R.NAMES)
-def test_blocks_match_reference_vectors(name):
+def test_blocks_match_reference_vectors(name, monkeypatch):
     g = R.RhGolden(name)
     m = _module(g)
     u = g.u.cuda().requires_grad_(True)
+    # the fused kernels must be what runs here (a silent fall-back to plain torch would pass the comparison as well)
+    import cnn_with_pde_amd.functional as F_
+    calls = []
+    orig = F_.sym_layer
+    monkeypatch.setattr(F_, "sym_layer", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
     y = m(u)
+    assert calls, "the module did not go through functional.sym_layer"
     y.backward(g.gy.cuda())
     torch.cuda.synchronize()
     errs = {"y": G.rel_err(y.detach().cpu(), g.y), "gu": G.rel_err(u.grad.cpu(), g.gu)}
@@ -112,7 +118,9 @@ def test_symmetric_layer_vs_oracle(B, D, act, training):
     Kd = Kw.cuda().requires_grad_(True)
     Xd = X.cuda().requires_grad_(True)
     bd = base.cuda().requires_grad_(True)
-    assert F_.sym_layer_supported(Xd, bn)
+    # the module-level policy sends batches above 128 rows (and what BatchNorm1d refuses) to plain torch; the kernels
+    # themselves, called here directly, serve every batch
+    assert F_.sym_layer_supported(Xd, bn) == (B <= F_.SYM_LAYER_MAX_ROWS)
     y = F_.sym_layer(Xd, Kd, bn, act, base=bd, scale=scale)
     y.backward(gy.cuda())
     torch.cuda.synchronize()
@@ -146,3 +154,16 @@ def test_boundary_rejects_what_it_cannot_do():
     assert lib.pde_sym_layer_forward(8, 64, 1, 0, p(x), p(k), p(v), p(v), None, None, 0.1, 1e-5, None, -1.0,
                                      p(x), p(x), p(v), p(v), p(x), st) == -1
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_training_batch_of_one_row_raises_like_the_reference():
+    """torch.nn.BatchNorm1d refuses a training-mode batch of one row (cifar_2version.py:202 goes through it): the
+    counterpart must not silently normalise it with the fused kernels."""
+    import cnn_with_pde_amd as P
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = P.SymmetricLayer(1, 8).cuda().train()
+    with pytest.raises(ValueError):
+        m(torch.randn(1, 1, 8, 8, device="cuda"))
+    m.eval()
+    assert m(torch.randn(1, 1, 8, 8, device="cuda")).shape == (1, 1, 8, 8)
