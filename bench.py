@@ -52,7 +52,9 @@ def build_layer(C, N, steps, dev, rank, mixing):
     return layer.to(dev)
 
 
-def run_steps(layer, u, gy, n, dist_on, flat):
+def run_steps(layer, u, gy, n, dist_on, flat, spans=None):
+    """`spans` (multi-rank runs): receives one (before, after) event pair per step around the wait for the gradient
+    all-reduce — what the stream waited for a collective that the backward's hooks had launched earlier."""
     for _ in range(n):
         if dist_on:
             flat.zero()                         # the gradients are views of the flat bucket: one launch clears them
@@ -68,7 +70,17 @@ def run_steps(layer, u, gy, n, dist_on, flat):
             # legs (some of their parameters receive no gradient) launch it here.
             if not flat._hooks:
                 flat.start(average=True)
-            flat.finish()
+            if spans is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                flat.finish()
+                e1.record()
+                spans.append((e0, e1))
+            else:
+                flat.finish()
+
+
+LAST_DIAG = {}        # per-rank figures of the latest timed() call on a multi-rank run (rank 0 puts them in the JSON line)
 
 
 def timed(layer, u, gy, steps, warmup, dist_on, flat):
@@ -78,15 +90,31 @@ def timed(layer, u, gy, steps, warmup, dist_on, flat):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run_steps(layer, u, gy, steps, dist_on, flat)
+    spans = [] if dist_on else None
+    run_steps(layer, u, gy, steps, dist_on, flat, spans)
     torch.cuda.synchronize()
+    own = time.perf_counter() - t0               # this rank alone, before it waits for the others
     if dist_on:
         dist.barrier()
     dt = time.perf_counter() - t0
+    LAST_DIAG.clear()
     if dist_on:
         t = torch.tensor([dt], device=u.device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # what a first multi-GPU run needs in order to be read: every rank's own step time and the part of it the
+        # stream spent waiting for the gradient all-reduce (the collective is launched from inside backward)
+        exposed = sum(a.elapsed_time(b) for a, b in spans) / max(len(spans), 1)
+        mine = torch.tensor([own / steps * 1e3, exposed], device=u.device, dtype=torch.float64)
+        allv = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(allv, mine)
+        per = [float(v[0]) for v in allv]
+        exp = [float(v[1]) for v in allv]
+        LAST_DIAG.update({"rank_ms_per_step": {"min": min(per), "max": max(per), "all": [round(x, 4) for x in per]},
+                          "allreduce_exposed_ms": {"mean": sum(exp) / len(exp), "max": max(exp),
+                                                   "note": "per step: stream time between the end of backward and the "
+                                                           "completion of the gradient all-reduce its hooks launched "
+                                                           "(events around GradBucket.finish())"}})
     return dt
 
 
@@ -421,6 +449,7 @@ def main():
         flat.attach_hooks(average=True)         # the all-reduce leaves from inside backward, behind the last gradient
 
     dt = timed(layer, u, gy, a.steps, a.warmup, dist_on, flat)
+    headline_diag = dict(LAST_DIAG)
     ms_step = dt / a.steps * 1e3
     samples_s = B * world * a.steps / dt
     elems = B * C * N * N
@@ -528,7 +557,8 @@ def main():
         gs = gy[: hi - lo].clone()
         dts = timed(layer, us, gs, a.steps, a.warmup, dist_on, flat)
         if rank == 0:
-            out["strong"] = {"scaling": "strong", "global_batch": B, "per_gpu_batch": hi - lo, "ms_per_step": dts / a.steps * 1e3,
+            out["dist"] = headline_diag
+            out["strong"] = {"dist": dict(LAST_DIAG),"scaling": "strong", "global_batch": B, "per_gpu_batch": hi - lo, "ms_per_step": dts / a.steps * 1e3,
                              "value": B * a.steps / dts / 1e6, "unit": "Msamples/s",
                              "note": "same layer, the global batch fixed at --batch and sharded over the ranks (contiguous "
                                      "shards, gradient all-reduce every step); `value` above is the weak-scaling line"}

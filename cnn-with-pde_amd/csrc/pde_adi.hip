@@ -419,8 +419,10 @@ __global__ __launch_bounds__(1024) void adi_pgrad_kernel(PgradArgs a) {
         // over the workgroups' partials and meet in a butterfly (fixed order).  One THREAD per output walking the
         // partials one dependent load after the other took 33 us for 128 workgroups.
         const int lane = tid & 63, wv = tid >> 6, nout = a.C * a.C + 2;
+        // These few scalars are whole-tensor sums that cancel heavily (seen: 2880 terms of total size 220 adding up to
+        // 0.0144): the partials are added in DOUBLE precision, so that the summation adds nothing to their fp32 rounding.
         for (int o = wv; o < nout; o += 16) {
-            float sum = 0.f;
+            double sum = 0.0;
             if (o < a.C * a.C) {
                 const int i = o / a.C, j = o % a.C;
                 for (int g = lane; g < a.gm_blocks; g += 64) sum += a.gm_part[((size_t)g * a.C + i) * kGmStride + j];
@@ -431,13 +433,13 @@ __global__ __launch_bounds__(1024) void adi_pgrad_kernel(PgradArgs a) {
             }
             for (int x = 32; x > 0; x >>= 1) sum += __shfl_xor(sum, x, 64);
             if (lane == 0) {
-                if (o < a.C * a.C) a.gM[o] = sum;
+                if (o < a.C * a.C) a.gM[o] = (float)sum;
                 else if (o == a.C * a.C) {
                     if (a.g_skip != nullptr) {
-                        const float sg = 1.0f / (1.0f + expf(-*a.skip_w));
-                        *a.g_skip = (1.0f - sg) * sum;     // the kernel's partials already carry one factor sigmoid
+                        const double sg = 1.0 / (1.0 + exp(-(double)*a.skip_w));
+                        *a.g_skip = (float)((1.0 - sg) * sum);     // the kernel's partials already carry one factor sigmoid
                     }
-                } else if (a.g_w != nullptr) *a.g_w = sum;
+                } else if (a.g_w != nullptr) *a.g_w = (float)sum;
             }
         }
         return;

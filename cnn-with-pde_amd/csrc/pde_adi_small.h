@@ -502,10 +502,10 @@ __global__ __launch_bounds__(64 * kSmallMaxC) void adi_small_bwd_kernel(SmallArg
         }
         float* gd = Lp->gm_part + ((size_t)b0 * nC + c) * kGmStride;
 #pragma unroll
-        for (int j = 0; j < kGmStride; ++j) {
-            float v = (j < kSmallMaxC) ? gm[j] : (j == kSmallMaxC ? gskip : wsum);
+        for (int j = 0; j < kGmStride; ++j) {                 // (the lanes' sums meet in double: these scalars cancel heavily)
+            double v = (j < kSmallMaxC) ? gm[j] : (j == kSmallMaxC ? gskip : wsum);
             for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-            if (lane == 0) gd[j] = v;
+            if (lane == 0) gd[j] = (float)v;
         }
     }
     dma_wait_all();

@@ -1,7 +1,11 @@
 // SVHN skip connection (SVHN.py:73-74): out = s*u0 + (1-s)*u,  s = sigmoid(skip_weight), in one pass
 // over the tensors (torch needs four elementwise kernels forward and six backward for it).
 //   backward:  g_u0 = s*g,  g_u = (1-s)*g,  g_skip_weight = s*(1-s) * sum g*(u0 - u)
-// The sum is taken per workgroup and added up in a fixed order by a second tiny kernel (no float atomics).
+// The sum is taken per workgroup and added up in a fixed order by a second tiny kernel (no float atomics).  It is a sum of
+// differences of nearly equal numbers that cancels heavily (u is u0 after a few small diffusion steps), so every stage of
+// it — per thread, per wave, per workgroup, over the workgroups — is carried in DOUBLE precision: what is left of the
+// scalar's error is the fp32 rounding of the layer's own output, not the summation (round 4; the kernel is bandwidth-bound,
+// the fp64 FMAs are free).
 #include "pde_common.h"
 
 namespace pde {
@@ -64,23 +68,23 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(const IO* __restrict__ u
 template <typename IO>
 __global__ __launch_bounds__(256) void blend_bwd_kernel(const IO* __restrict__ g, const IO* __restrict__ u0, const IO* __restrict__ u,
                                                         const float* __restrict__ skip_weight, IO* __restrict__ g_u0,
-                                                        IO* __restrict__ g_u, float* __restrict__ part, size_t n) {
-    __shared__ float sh[4];
+                                                        IO* __restrict__ g_u, double* __restrict__ part, size_t n) {
+    __shared__ double sh[4];
     const float s = sigmoidf(*skip_weight), t = 1.0f - s;
     const size_t stride = (size_t)gridDim.x * 256 * 8;
-    float acc = 0.f;
+    double acc = 0.0;
     for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += stride) {
         if (i + 8 <= n) {
             float gg[8], a[8], b[8], o0[8], o1[8];
             Vec<IO>::ld(g + i, gg); Vec<IO>::ld(u0 + i, a); Vec<IO>::ld(u + i, b);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { o0[k] = s * gg[k]; o1[k] = t * gg[k]; acc = fmaf(gg[k], a[k] - b[k], acc); }
+            for (int k = 0; k < 8; ++k) { o0[k] = s * gg[k]; o1[k] = t * gg[k]; acc = fma((double)gg[k], (double)a[k] - (double)b[k], acc); }
             Vec<IO>::st(g_u0 + i, o0); Vec<IO>::st(g_u + i, o1);
         } else {
             for (size_t j = i; j < n; ++j) {
                 const float gj = Vec<IO>::ld1(g + j);
                 Vec<IO>::st1(g_u0 + j, s * gj); Vec<IO>::st1(g_u + j, t * gj);
-                acc = fmaf(gj, Vec<IO>::ld1(u0 + j) - Vec<IO>::ld1(u + j), acc);
+                acc = fma((double)gj, (double)Vec<IO>::ld1(u0 + j) - (double)Vec<IO>::ld1(u + j), acc);
             }
         }
     }
@@ -90,17 +94,17 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(const IO* __restrict__ g
     if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
-__global__ __launch_bounds__(256) void blend_reduce_kernel(const float* __restrict__ part, int nparts,
+__global__ __launch_bounds__(256) void blend_reduce_kernel(const double* __restrict__ part, int nparts,
                                                            const float* __restrict__ skip_weight, float* __restrict__ g_w) {
-    __shared__ float sh[4];
-    float acc = 0.f;
+    __shared__ double sh[4];
+    double acc = 0.0;
     for (int i = threadIdx.x; i < nparts; i += 256) acc += part[i];
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const float s = sigmoidf(*skip_weight);
-        *g_w = s * (1.0f - s) * ((sh[0] + sh[1]) + (sh[2] + sh[3]));
+        const double s = 1.0 / (1.0 + exp(-(double)*skip_weight));
+        *g_w = (float)(s * (1.0 - s) * ((sh[0] + sh[1]) + (sh[2] + sh[3])));
     }
 }
 
@@ -130,7 +134,7 @@ int pde_skip_blend_forward(int64_t n, int32_t io_dtype, const void* u0, const vo
     return check_launch();
 }
 
-size_t pde_skip_blend_backward_workspace_bytes(int64_t n) { return n > 0 ? (size_t)blend_grid((size_t)n) * sizeof(float) : 0; }
+size_t pde_skip_blend_backward_workspace_bytes(int64_t n) { return n > 0 ? (size_t)blend_grid((size_t)n) * sizeof(double) : 0; }
 
 int pde_skip_blend_backward(int64_t n, int32_t io_dtype, const void* g, const void* u0, const void* u, const float* skip_weight,
                             void* g_u0, void* g_u, float* g_skip_weight, void* workspace, size_t workspace_bytes, void* stream) {
@@ -138,7 +142,8 @@ int pde_skip_blend_backward(int64_t n, int32_t io_dtype, const void* g, const vo
     if (workspace_bytes < pde_skip_blend_backward_workspace_bytes(n)) return PDE_E_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int grid = blend_grid((size_t)n);
-    float* part = static_cast<float*>(workspace);
+    if ((uintptr_t)workspace & 7) return PDE_E_WORKSPACE;
+    double* part = static_cast<double*>(workspace);
     if (io_dtype == PDE_IO_F32)
         hipLaunchKernelGGL(blend_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)g, (const float*)u0, (const float*)u, skip_weight, (float*)g_u0, (float*)g_u, part, (size_t)n);
     else if (io_dtype == PDE_IO_BF16)

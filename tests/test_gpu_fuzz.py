@@ -63,6 +63,26 @@ def _build(kind, N, C, steps, dt, dx):
     return layer, spec
 
 
+# Three cases from wider seeded walks of round 3 (seeds 2026 and 99, 889 cases each) whose few-entry gradients fall
+# outside the window above.  Round 4 carried every stage of those sums in double precision (pde_blend.hip, the epilogue of
+# the C <= 4 kernels, adi_pgrad_kernel) and the figures did not move (2.9e-5 -> 2.8e-5, 1.6e-4 -> 1.6e-4, 2.06e-5 ->
+# 2.12e-5): the summation is not what limits them.  Each is sigma'(w) * sum g.(u0 - u_K), or sum g.u of a 1 x 1 operator, of
+# a layer whose output differs from its input by ~1e-3: the scalar inherits the fp32 rounding of the STATES (the two-sided
+# elimination multiplies by stored reciprocals where the reference divides: about one rounding more per sweep), amplified
+# by the cancellation — 3-8 times the reference's own fp32 distance from the fp64 value on these three.  They are pinned
+# here with the bounds they meet, so that a regression (or an improvement of the sweeps' rounding) shows.
+PINNED = [
+    (("svhn", 12, 8, 1, 0.02, 2.0, 1.0, 5.0, 17), 4e-5),       # skip weight: 2.8e-5 from fp64 (reference's fp32: 7.0e-6)
+    (("svhn", 28, 16, 3, 0.1, 2.0, 1.0, 0.0, 1), 2.5e-4),       # skip weight: 1.6e-4 (1.9e-5); B = 1, u_K within 2e-3 of u0
+    (("cifar10", 16, 1, 3, 0.4, 1.0, 1.0, 0.0, 1), 3e-5),       # 1 x 1 operator: 2.1e-5 (1.8e-6)
+]
+
+
+@pytest.mark.parametrize("case,limit", PINNED, ids=lambda c: "-".join(str(x) for x in c) if isinstance(c, tuple) else str(c))
+def test_pinned_cancelling_scalar_gradients(case, limit):
+    check_case(case, small_limit=limit)
+
+
 def _cases():
     rng = random.Random(SEED)
     return [_draw(rng) for _ in range(CASES)]
@@ -73,8 +93,9 @@ def test_random_case_vs_oracle(case):
     check_case(case)
 
 
-def check_case(case):
-    """One drawn layer call against the oracle (also used by tests/test_gpu_anysize.py for the other line lengths)."""
+def check_case(case, small_limit=None):
+    """One drawn layer call against the oracle (also used by tests/test_gpu_anysize.py for the other line lengths).
+    ``small_limit``: the pinned cases' own bound on the few-entry gradients (see PINNED)."""
     kind, N, C, steps, dt, dx, scale, slope, B = case
     g = torch.Generator().manual_seed(zlib.crc32(repr(case).encode()))
     layer, spec = _build(kind, N, C, steps, dt, dx)
@@ -117,7 +138,8 @@ def check_case(case):
             errs["g_" + n] = G.rel_err(dl.get_parameter(n).grad.cpu().reshape(gp64[n].shape), gp64[n])
             o32 = G.rel_err(gp_ref[n], gp64[n])
             errs["oracle32_vs_64_" + n] = o32                                     # reported with a failure
-            limits["g_" + n] = max(2e-5, 4.0 * o32)
+            # (capped: a noisy fp32 oracle must not open the window without bound)
+            limits["g_" + n] = small_limit if small_limit is not None else min(max(2e-5, 4.0 * o32), 1e-4)
             limits["oracle32_vs_64_" + n] = float("inf")
     bad = {k: (v, limits.get(k, 1e-5)) for k, v in errs.items() if not v <= limits.get(k, 1e-5)}
     assert not bad, (bad, {k: v for k, v in errs.items() if k.startswith("oracle32")})
@@ -169,7 +191,7 @@ def test_random_explicit_case_vs_oracle(case):
                                            {k: v.double() for k, v in params.items()}, gy.double())
             for n in small:
                 errs["g_" + n] = G.rel_err(getattr(dl, n).grad.float().cpu(), gp64[n])
-                limits["g_" + n] = max(2e-5, 4.0 * G.rel_err(gp_ref[n], gp64[n]))
+                limits["g_" + n] = min(max(2e-5, 4.0 * G.rel_err(gp_ref[n], gp64[n])), 1e-4)
     bad = {k: (v, limits[k]) for k, v in errs.items() if not v <= limits[k]}
     assert not bad, (bad, errs)
 
