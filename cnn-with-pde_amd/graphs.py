@@ -36,12 +36,68 @@ def freeze_checkpoint_plans(module, *example_inputs):
     return {ly: ly.freeze_checkpoint_plan() for ly in _pde_layers(module)}
 
 
+class _capture_guard:
+    """What this module does around every stream capture.
+
+    Record (round 3, gpurun_out/r3_crash.log): ONE run of tests/test_gpu_graphs.py died with SIGSEGV inside
+    ``torch.cuda.CUDAGraph.capture_end`` (torch/cuda/graphs.py:130, called from ``GraphedStep.__init__``) in the fourth
+    capture of the process; the only other thread had no Python frame — the autograd engine's device worker, which had
+    just run the captured backward.  It never showed again, and a fault must not be hunted by re-running, so the cause is
+    argued from that record, not demonstrated:
+
+    * the library's captured entry points are launches only (no allocation, copy, event query or synchronisation: every
+      ``hipMalloc`` / ``hipMemcpy`` / ``hipEventSynchronize`` of csrc/ sits in diagnostics or in the eager-only paths that a
+      frozen checkpoint plan switches off), so nothing of ours runs inside ``hipStreamEndCapture``;
+    * a SIGSEGV (not the SIGABRT of an exception leaving a destructor) in the capturing thread while a second, non-Python
+      thread is alive fits a RACE between ``capture_end`` and that worker still releasing the finished backward's
+      buffers — ``torch.autograd.grad`` returns when the graph task is marked complete, the worker drops its own reference
+      to the task (saved tensors -> caching-allocator frees into the capture's private pool) after that;
+    * it also fits the cyclic collector destroying an unreachable ``CUDAGraph`` of an earlier test
+      (``make_graphed_callables`` leaves its graphs in reference cycles) from inside the capture.
+
+    Both windows are closed: (1) collect, then keep the cyclic collector off, for the length of the capture; (2) before the
+    capture ends, push one kernel-less task through the same device worker and wait for it — the worker takes tasks in
+    order and lets go of a finished graph task before it picks up the next, so when that task returns nothing of the
+    captured backward is left in the worker's hands.  tests/test_gpu_graphs.py::test_capture_with_cyclic_garbage_around
+    sets up the conditions (a graphed callable kept only by a reference cycle, a backward inside the capture) in a child
+    interpreter."""
+
+    def __enter__(self):
+        gc.collect()
+        self.was_on = gc.isenabled()
+        gc.disable()
+        return self
+
+    def __exit__(self, *exc):
+        if self.was_on:
+            gc.enable()
+        return False
+
+
+_flush_leaf = {}
+
+
+def _quiesce_autograd_worker(device=None):
+    """One view-only backward through the device's autograd worker (no kernel, nothing captured): returns once the worker
+    has released whatever it ran before."""
+    dev = torch.cuda.current_device() if device is None else device
+    leaf = _flush_leaf.get(dev)
+    if leaf is None:                   # (allocated outside any capture: GraphedStep / make_graphed create it up front)
+        leaf = _flush_leaf[dev] = torch.zeros(1, device=f"cuda:{dev}", requires_grad=True)
+    torch.autograd.grad(leaf.view(1), leaf, leaf.detach())     # a view's backward is a view: no launch, no allocation
+
+
 def make_graphed(module, *sample_args, num_warmup_iters=3):
     """``torch.cuda.make_graphed_callables`` for a module built from the PDE layers: plans frozen first, then the
     forward and the backward are captured (one graph each) and replayed on every call.  Shapes, dtypes and the
-    requires_grad pattern of the arguments are those of ``sample_args`` from then on."""
+    requires_grad pattern of the arguments are those of ``sample_args`` from then on.  The captures run under the same
+    guard as ``GraphedStep`` (no cyclic collection while a stream is capturing; see ``_capture_guard``)."""
     freeze_checkpoint_plans(module, *sample_args)
-    return torch.cuda.make_graphed_callables(module, tuple(sample_args), num_warmup_iters=num_warmup_iters)
+    _quiesce_autograd_worker()
+    with _capture_guard():
+        out = torch.cuda.make_graphed_callables(module, tuple(sample_args), num_warmup_iters=num_warmup_iters)
+    _quiesce_autograd_worker()
+    return out
 
 
 class GraphedStep:
@@ -62,19 +118,11 @@ class GraphedStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        # No cyclic garbage collection while the stream is capturing: an unreachable CUDAGraph of an earlier step (torch's
-        # graphed callables sit in reference cycles) destroyed from inside the capture — e.g. by a collection that a
-        # backward running in the autograd thread happens to trigger — is "operation not permitted when stream is
-        # capturing" raised from a destructor, i.e. the process aborts.
-        gc.collect()
-        was_on = gc.isenabled()
-        gc.disable()
-        try:
+        _quiesce_autograd_worker()                       # (creates its leaf outside the capture)
+        with _capture_guard():                           # see there: what the round-3 crash record says and does not say
             with torch.cuda.graph(self.graph):
                 outs = fn()
-        finally:
-            if was_on:
-                gc.enable()
+                _quiesce_autograd_worker()               # the worker has let go of the captured backward before capture_end
         # Keep the static buffers, not the autograd graph of the capture: an output with a grad_fn would keep the capture
         # stream's AccumulateGrad nodes of the leaves alive, and the next eager backward over the same leaves (on another
         # stream) would trip over them ("AccumulateGrad node's stream does not match ...").

@@ -243,3 +243,68 @@ def test_shared_input_backward_notices_in_place_changes():
         layers[0].alpha_base.mul_(1.5)
     with pytest.raises(RuntimeError, match="modified by an inplace operation"):
         out.sum().backward()
+
+
+CYCLE_CHILD = r"""
+import contextlib, gc, io, sys, weakref
+sys.path[:0] = [%(root)r, %(tests)r]
+import torch
+import cnn_with_pde_amd as P
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+g = torch.Generator().manual_seed(3)
+x = torch.randn(4, 3, 32, 32, generator=g).cuda()
+# 1. a graphed callable that only a reference cycle keeps alive (what torch.cuda.make_graphed_callables leaves behind
+#    once its caller drops it), collectable but not yet collected when the next capture starts
+gc.disable()
+layer0 = quiet(P.SvhnDiffusionLayer, 32, 3, dt=0.01, num_steps=2).cuda()
+graphed = P.make_graphed(layer0, x.clone().requires_grad_(True))
+graphed(x.clone().requires_grad_(True)).sum().backward()
+class Box: pass
+box = Box(); box.self = box; box.fn = graphed
+probe = weakref.ref(box)
+del box, graphed
+assert probe() is not None            # unreachable, still there
+gc.enable()
+# 2. a capture with a backward inside (the autograd worker runs it), under the guard
+layer = quiet(P.EnhancedDiffusionLayer, 32, 3, dt=0.6, num_steps=3).cuda()     # large coefficients: a checkpointed backward
+xs = x.clone().requires_grad_(True)
+gy = torch.randn(4, 3, 32, 32, generator=g).cuda()
+params = list(layer.parameters())
+def fn():
+    return torch.autograd.grad(layer(xs), [xs] + params, gy)
+ref = [t.detach().clone() for t in fn()]
+layer.freeze_checkpoint_plan(xs)
+step = P.GraphedStep(fn)
+assert probe() is None                # the guard collected the cycle BEFORE the stream started capturing
+for _ in range(3):
+    got = step()
+torch.cuda.synchronize()
+for a, b in zip(got, ref):          # (the frozen plan may park other states than the automatic one: rounding-level differences)
+    assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()), float((a - b).abs().max())
+# 3. the same around make_graphed
+box = Box(); box.self = box; box.fn = step
+probe = weakref.ref(box)
+del box, step
+g2 = P.make_graphed(layer, x.clone().requires_grad_(True))
+assert probe() is None
+g2(x.clone().requires_grad_(True)).sum().backward()
+torch.cuda.synchronize()
+print("capture guard ok")
+"""
+
+
+def test_capture_with_cyclic_garbage_around():
+    """The conditions the capture guard of cnn_with_pde_amd.graphs exists for (see _capture_guard): an unreachable
+    graphed callable in a reference cycle when a capture starts, and a backward inside the capture.  In a child
+    interpreter: a failure here is a dead process, not an exception."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = CYCLE_CHILD % {"root": os.path.dirname(here), "tests": here}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "capture guard ok" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
