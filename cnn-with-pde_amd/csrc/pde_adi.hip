@@ -682,6 +682,10 @@ int dispatch_bwd(const PdeAdiDesc* d, int split, const SweepArgs& sa, int grid, 
 
 int count_ckpt(const uint64_t m[2]) { return m ? __builtin_popcountll(m[0]) + __builtin_popcountll(m[1]) : 0; }
 
+bool asm_fwd_eligible(const PdeAdiDesc* d) {
+    return asm_fwd_enabled() && d->N == 32 && d->io_dtype == PDE_IO_F32 && split_of(d) == kSplitStrang && d->num_sweeps >= 6;
+}
+
 // ---- launch helpers shared by the whole-schedule entry points and the per-step ones -----------------
 // forward sweeps of `d` (a whole schedule or one step of it) with records/table already in place
 int launch_fwd_sweeps(const PdeAdiDesc* d, const void* u, void* y, const float* coef, const SweepTab* tab,
@@ -693,6 +697,19 @@ int launch_fwd_sweeps(const PdeAdiDesc* d, const void* u, void* y, const float* 
     sa.one_eps = 1.0f + d->eps;
     sa.xcd_map = use_xcd_map(d);
     sa.pair_x = (split_of(d) == kSplitStrang && strang_pairs_identical(d)) ? 1 : 0;
+    // N = 32, fp32 tensors, Strang schedules of two or more steps: the hand-scheduled assembly kernel (gen_adi_fwd_asm.py:
+    // 16 waves, four planes per lane, rows held in registers, the record ring handed over by counters)
+    if (asm_fwd_eligible(d)) {
+        AsmBwdArgs aa{};
+        aa.gy = u; aa.y = y; aa.coef = coef;
+        aa.B = d->B; aa.C = d->C; aa.S = d->num_sweeps;
+        aa.nchunk = (d->B + kAsmFwdPlanes - 1) / kAsmFwdPlanes;
+        aa.G = groups_per_channel(d, kAsmFwdPlanes, 1);
+        aa.K = d->num_sweeps / 3;
+        aa.acc_part = sa.pair_x ? 2 : 0;
+        const int xcd = sa.xcd_map;
+        return timed_launch([&]() -> int { return asm_fwd_launch(aa, xcd, st); }, st, true, true);
+    }
     const size_t lds = (size_t)(kRing * kRecFwdPad + kWaves * kImage) * sizeof(float);
     return dispatch_fwd(d, split_of(d), sa, sa.G * d->C, lds, st);
 }

@@ -55,7 +55,7 @@ def main():
     import numpy as np
     outs = {}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    for tag, env in (("hip", {"PDE_ASM_BWD": "0"}), ("asm12", {"PDE_ASM_BWD": "1", "PDE_ASM_VARIANT": "12"}),
+    for tag, env in (("hip", {"PDE_ASM_BWD": "0", "PDE_ASM_FWD": "0"}), ("asm12", {"PDE_ASM_BWD": "1", "PDE_ASM_VARIANT": "12"}),
                      ("asm8b", {"PDE_ASM_BWD": "1", "PDE_ASM_VARIANT": "8b"})):
         out = os.path.join(ROOT, "gpurun_out", f"asmchk_{tag}.npz")
         print("==", tag, flush=True)

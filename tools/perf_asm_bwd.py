@@ -40,7 +40,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "child":
         child()
         sys.exit(0)
-    specs = sys.argv[1:] or ["hip=PDE_ASM_BWD=0", "asm8=PDE_ASM_VARIANT=8", "asm12=PDE_ASM_VARIANT=12"]
+    specs = sys.argv[1:] or ["hip=PDE_ASM_BWD=0,PDE_ASM_FWD=0", "asm8=PDE_ASM_VARIANT=8", "asm12=PDE_ASM_VARIANT=12"]
     for spec in specs:
         tag, _, envs = spec.partition("=")
         env = dict(os.environ)
