@@ -35,7 +35,7 @@ int asm_bwd_launch(int nw, const AsmBwdArgs& a, int xcd_map, hipStream_t st);
 
 // The forward counterpart (gen_adi_fwd_asm.py: 16 waves, four planes per lane).  Same argument block: gy = the input u,
 // y = the output, coef, B, C, S, G, K, nchunk = ceil(B / 64), acc_part bit 1 = twin records; the other fields unused.
-bool asm_fwd_enabled();                        // PDE_ASM_FWD=0 switches it off
+bool asm_fwd_enabled();                        // opt-in: PDE_ASM_FWD=1 (no faster than the HIP forward, see pde_adi_asm.hip)
 constexpr int kAsmFwdPlanes = 64;              // planes a workgroup takes per pass
 int asm_fwd_launch(const AsmBwdArgs& a, int xcd_map, hipStream_t st);
 

@@ -139,7 +139,9 @@ def test_against_the_hip_kernel_it_replaces(tmp_path):
     """Same inputs through both kernels, each in its own interpreter (the switch is read once per process)."""
     here = os.path.dirname(os.path.abspath(__file__))
     res = {}
-    for tag, env in (("hip", {"PDE_ASM_BWD": "0"}), ("asm", {"PDE_ASM_BWD": "1"})):
+    # (the "asm" child also takes the opt-in assembly FORWARD, gen_adi_fwd_asm.py: its output must equal the HIP forward's
+    #  bit for bit — the `torch.equal(y0, y1)` below)
+    for tag, env in (("hip", {"PDE_ASM_BWD": "0", "PDE_ASM_FWD": "0"}), ("asm", {"PDE_ASM_BWD": "1", "PDE_ASM_FWD": "1"})):
         path = str(tmp_path / f"{tag}.pt")
         code = CHILD % {"root": os.path.dirname(here), "tests": here, "path": path}
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
