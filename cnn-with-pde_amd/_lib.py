@@ -141,6 +141,34 @@ def load():
     return lib
 
 
+#: the native host path of the launch-bound layer calls (csrc/host_ext.cpp: torch C++ autograd nodes over the same C ABI).
+#: Host glue only — the same launches as the ctypes path, without the interpreter between them.  PDE_HOST_EXT=0 keeps
+#: every call on the ctypes path; a developer override of the library (PDECNN_LIB) does too, since the extension is linked
+#: against the in-tree build.
+HOST_EXT_PATH = os.path.join(HERE, "lib", "_pdecnn_host.so")
+_host = None
+
+
+def host_ext():
+    """The extension module, or None when it is switched off.  Raises when it should be there and is not."""
+    global _host
+    if _host is None:
+        if os.environ.get("PDE_HOST_EXT", "1") == "0" or os.environ.get("PDECNN_LIB"):
+            _host = False
+        else:
+            if not os.path.isfile(HOST_EXT_PATH):
+                raise PdeError(f"{HOST_EXT_PATH} not found: build it with `make -C cnn-with-pde_amd/csrc` "
+                               "(or set PDE_HOST_EXT=0 to run every call through the ctypes path)")
+            load()                                  # libpdecnn_hip.so first: the extension resolves its symbols from it
+            import importlib.util
+            import torch  # noqa: F401  (libtorch must be loaded before the extension)
+            spec = importlib.util.spec_from_file_location("_pdecnn_host", HOST_EXT_PATH)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            _host = mod
+    return _host or None
+
+
 def check(rc, what):
     if rc != 0:
         raise PdeError(f"{what} failed: {ERRORS.get(rc, rc)}")

@@ -1,0 +1,626 @@
+// Native host path of the launch-bound layer calls: the autograd node of one implicit diffusion layer
+// (functional.adi_diffuse: mnist_test.py:44-198, fashion_mnist.py:18-196, the C = 1 shapes the reference trains on) written
+// against torch's C++ autograd and the C ABI of include/pdecnn.h.  Same calls, same arguments and the same order of
+// launches as functional._AdiFn (which stays the general path: coefficient-maxima sinks, lagged plans); what goes is the
+// interpreter between them — at (64,1,28,28) the kernels of a forward + backward take 0.1 ms on the device and the Python
+// around them 0.17 ms on the host.
+//
+// Nothing here computes: tensors are allocated through torch's caching allocator, every result comes from the HIP kernels
+// of libpdecnn_hip.so on torch's current stream.
+#include <torch/extension.h>
+#include <ATen/hip/HIPContext.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <hip/hip_runtime_api.h>
+
+#include <atomic>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include "../../include/pdecnn.h"
+
+namespace {
+
+using torch::Tensor;
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+
+const char* err_text(int rc) {
+    switch (rc) {
+        case -1: return "PDE_E_BADARG (null pointer, bad dimension or enum)";
+        case -2: return "PDE_E_UNSUPPORTED_N";
+        case -3: return "PDE_E_TOO_MANY_SWEEPS";
+        case -4: return "PDE_E_LAUNCH (HIP launch failed)";
+        case -5: return "PDE_E_WORKSPACE (workspace too small or misaligned)";
+    }
+    return "unknown error";
+}
+
+void check(int rc, const char* what) {
+    TORCH_CHECK(rc == 0, what, " failed: ", err_text(rc), " (", rc, ")");
+}
+
+// ---- the way the per-sweep coefficient maxima reach the host: pinned slots, one event each -------------------------------
+// pde_adi_forward writes the maxima into the slot and records the event right behind its factorisation kernel; the
+// backward plans its checkpoints from them (functional.plan_checkpoints).  A slot is held from a forward until its node
+// dies (a tensor over the slot's memory, kept in the node, hands it back from its deleter).
+struct Slot {
+    float* host = nullptr;
+    hipEvent_t ev = nullptr;
+    std::atomic<bool> busy{false};
+    bool pooled = true;
+};
+
+constexpr int kRing = 256;
+constexpr int kSlotFloats = PDE_MAX_SWEEPS * 4;
+
+struct Ring {
+    std::mutex mu;
+    std::vector<std::unique_ptr<Slot>> slots;
+    float* pool = nullptr;
+    int next = 0;
+};
+
+Ring* ring_of(int dev) {
+    static std::mutex mu;
+    static std::vector<std::unique_ptr<Ring>> rings;
+    std::lock_guard<std::mutex> g(mu);
+    if ((int)rings.size() <= dev) rings.resize(dev + 1);
+    if (!rings[dev]) {
+        auto r = std::make_unique<Ring>();
+        TORCH_CHECK(hipHostMalloc((void**)&r->pool, sizeof(float) * kSlotFloats * kRing, hipHostMallocDefault) == hipSuccess,
+                    "hipHostMalloc of the coefficient-maxima ring failed");
+        for (int i = 0; i < kRing; ++i) {
+            auto s = std::make_unique<Slot>();
+            s->host = r->pool + (size_t)i * kSlotFloats;
+            TORCH_CHECK(hipEventCreateWithFlags(&s->ev, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
+            r->slots.push_back(std::move(s));
+        }
+        rings[dev] = std::move(r);
+    }
+    return rings[dev].get();
+}
+
+Slot* acquire_slot(int dev) {
+    Ring* r = ring_of(dev);
+    {
+        std::lock_guard<std::mutex> g(r->mu);
+        for (int off = 0; off < kRing; ++off) {
+            int i = (r->next + off) % kRing;
+            Slot* s = r->slots[i].get();
+            if (!s->busy.load(std::memory_order_acquire)) {
+                s->busy.store(true, std::memory_order_release);
+                r->next = (i + 1) % kRing;
+                return s;
+            }
+        }
+    }
+    // every slot is held by a node whose backward is outstanding: a slot of its own, freed with the node
+    Slot* s = new Slot();
+    s->pooled = false;
+    s->busy.store(true);
+    TORCH_CHECK(hipHostMalloc((void**)&s->host, sizeof(float) * kSlotFloats, hipHostMallocDefault) == hipSuccess,
+                "hipHostMalloc failed");
+    TORCH_CHECK(hipEventCreateWithFlags(&s->ev, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
+    return s;
+}
+
+void release_slot(Slot* s) {
+    if (s->pooled) {
+        s->busy.store(false, std::memory_order_release);
+        return;
+    }
+    (void)hipEventDestroy(s->ev);
+    (void)hipHostFree(s->host);
+    delete s;
+}
+
+// A CPU tensor over the slot's pinned floats whose deleter returns the slot: stored in the node, it ties the slot's
+// life to the node's without a class registration.
+Tensor slot_ticket(Slot* s, int n) {
+    return at::from_blob(s->host, {n}, [s](void*) { release_slot(s); }, at::TensorOptions().dtype(at::kFloat));
+}
+
+void wait_event(hipEvent_t ev) {
+    // expected within microseconds (the factorisation kernel right behind the forward's launch): poll before blocking
+    for (int i = 0; i < 20000; ++i)
+        if (hipEventQuery(ev) == hipSuccess) return;
+    TORCH_CHECK(hipEventSynchronize(ev) == hipSuccess, "hipEventSynchronize failed");
+}
+
+// functional.plan_checkpoints: bit s set = keep the state after sweep s instead of rebuilding it
+void plan_checkpoints(const float* kmax, int n, double amax, uint64_t mask[2]) {
+    mask[0] = mask[1] = 0;
+    double amp = 1.0;
+    for (int s = n - 1; s >= 1; --s) {
+        amp *= 1.0 + 4.0 * (double)kmax[s];
+        if (amp > amax) {
+            int b = s - 1;
+            mask[b >> 6] |= 1ull << (b & 63);
+            amp = 1.0;
+        }
+    }
+}
+
+int popcount2(const uint64_t m[2]) { return __builtin_popcountll(m[0]) + __builtin_popcountll(m[1]); }
+
+// functional._as_chw: (C,N,N) fp32 contiguous view of a coefficient tensor given as (N,N), (1,N,N) or (C,N,N)
+Tensor as_chw(const Tensor& p, int64_t C, int64_t N) {
+    Tensor q = p.detach();
+    if (q.dim() == 2) q = q.unsqueeze(0);
+    TORCH_CHECK(q.dim() == 3 && q.size(0) == C && q.size(1) == N && q.size(2) == N, "coefficient of shape ", p.sizes(),
+                " does not match (", C, ",", N, ",", N, ")");
+    if (q.scalar_type() != at::kFloat) q = q.to(at::kFloat);
+    return q.contiguous();
+}
+
+Tensor bytes(size_t n, const Tensor& like) {
+    return at::empty({(int64_t)std::max<size_t>(n, 256)}, like.options().dtype(at::kByte));
+}
+
+struct AdiFn : public torch::autograd::Function<AdiFn> {
+    // ckpt_mode: 0 = explicit mask (ckpt_lo/hi), 1 = "auto" (planned in the backward from this call's coefficients)
+    static Tensor forward(AutogradContext* ctx, const Tensor& u_in, const Tensor& ab, const Tensor& bb, const Tensor& asl,
+                          const Tensor& bsl, int64_t desc_addr, int64_t ckpt_mode, int64_t ckpt_lo, int64_t ckpt_hi,
+                          double amax, bool need_grad) {
+        TORCH_CHECK(u_in.is_cuda() && ab.is_cuda() && bb.is_cuda() && asl.is_cuda() && bsl.is_cuda(),
+                    "libpdecnn_hip operators need CUDA/HIP tensors (there is no CPU fallback)");
+        TORCH_CHECK(u_in.dim() == 4 && u_in.size(2) == u_in.size(3), "expected (B,C,N,N), got ", u_in.sizes());
+        PdeAdiDesc d;
+        std::memcpy(&d, reinterpret_cast<const void*>(desc_addr), sizeof(d));
+        const int64_t B = u_in.size(0), C = u_in.size(1), N = u_in.size(2);
+        Tensor u = u_in.detach();
+        if (u.scalar_type() != at::kFloat && u.scalar_type() != at::kBFloat16) u = u.to(at::kFloat);
+        u = u.contiguous();
+        TORCH_CHECK(d.B == B && d.C == C && d.N == N && d.io_dtype == (u.scalar_type() == at::kBFloat16 ? PDE_IO_BF16 : PDE_IO_F32),
+                    "descriptor does not match the tensor");
+        Tensor p[4] = {as_chw(ab, C, N), as_chw(bb, C, N), as_chw(asl, C, N), as_chw(bsl, C, N)};
+        const bool want_kmax = need_grad && ckpt_mode == 1;
+        c10::hip::HIPGuardMasqueradingAsCUDA guard(u.device());
+        hipStream_t st = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(u.device().index()).stream();
+        Tensor y = at::empty_like(u);
+        Tensor ws = bytes(pde_adi_forward_workspace_bytes(&d), u);
+        Tensor kdev, ticket;
+        Slot* slot = nullptr;
+        if (want_kmax) {
+            kdev = at::empty({(int64_t)d.num_sweeps}, u.options().dtype(at::kFloat));
+            slot = acquire_slot(u.device().index());
+            ticket = slot_ticket(slot, d.num_sweeps);
+        }
+        check(pde_adi_forward(&d, u.data_ptr(), y.data_ptr(), p[0].data_ptr<float>(), p[1].data_ptr<float>(),
+                              p[2].data_ptr<float>(), p[3].data_ptr<float>(), want_kmax ? kdev.data_ptr<float>() : nullptr,
+                              slot ? slot->host : nullptr, slot ? (void*)slot->ev : nullptr, ws.data_ptr(), (size_t)ws.numel(),
+                              (void*)st),
+              "pde_adi_forward");
+        if (need_grad) {
+            const bool explicit_none = ckpt_mode == 0 && ckpt_lo == 0 && ckpt_hi == 0;
+            ctx->save_for_backward({y, explicit_none ? Tensor() : u, p[0], p[1], p[2], p[3]});
+            ctx->saved_data["ws"] = ws;                      // the factorisation, reused by the backward
+            if (slot) {
+                ctx->saved_data["ticket"] = ticket;
+                ctx->saved_data["slot"] = (int64_t) reinterpret_cast<intptr_t>(slot);
+            }
+            ctx->saved_data["desc"] = std::string(reinterpret_cast<const char*>(&d), sizeof(d));
+            ctx->saved_data["ckpt"] = std::vector<int64_t>{ckpt_mode, ckpt_lo, ckpt_hi};
+            ctx->saved_data["amax"] = amax;
+            ctx->saved_data["sh0"] = ab.sizes().vec();
+            ctx->saved_data["sh1"] = bb.sizes().vec();
+            ctx->saved_data["sh2"] = asl.sizes().vec();
+            ctx->saved_data["sh3"] = bsl.sizes().vec();
+        }
+        return y;
+    }
+
+    static variable_list backward(AutogradContext* ctx, variable_list grads) {
+        auto saved = ctx->get_saved_variables();
+        const Tensor &y = saved[0], &u = saved[1];
+        PdeAdiDesc d;
+        std::memcpy(&d, ctx->saved_data["desc"].toStringRef().data(), sizeof(d));
+        auto ck = ctx->saved_data["ckpt"].toIntVector();
+        uint64_t mask[2] = {(uint64_t)ck[1], (uint64_t)ck[2]};
+        if (ck[0] == 1) {
+            Slot* slot = reinterpret_cast<Slot*>((intptr_t)ctx->saved_data["slot"].toInt());
+            wait_event(slot->ev);
+            plan_checkpoints(slot->host, d.num_sweeps, ctx->saved_data["amax"].toDouble(), mask);
+        }
+        const bool any = (mask[0] | mask[1]) != 0;
+        TORCH_CHECK(!any || u.defined(), "a checkpoint plan needs the layer input, which was not kept");
+        c10::hip::HIPGuardMasqueradingAsCUDA guard(y.device());                 // autograd's worker thread: set the device, fetch the stream here
+        hipStream_t st = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(y.device().index()).stream();
+        Tensor gy = grads[0];
+        if (gy.scalar_type() != y.scalar_type()) gy = gy.to(y.scalar_type());
+        gy = gy.contiguous();
+        Tensor gu = at::empty_like(y);
+        static const char* const kShape[4] = {"sh0", "sh1", "sh2", "sh3"};
+        Tensor gp[4];
+        for (int i = 0; i < 4; ++i) gp[i] = at::empty(ctx->saved_data[kShape[i]].toIntVector(), saved[2 + i].options());
+        Tensor ws = bytes(pde_adi_backward_workspace_bytes(&d, popcount2(mask)), y);
+        Tensor fws = ctx->saved_data["ws"].toTensor();
+        check(pde_adi_backward(&d, gy.data_ptr(), y.data_ptr(), any ? u.data_ptr() : nullptr, mask, gu.data_ptr(),
+                               saved[2].data_ptr<float>(), saved[3].data_ptr<float>(), saved[4].data_ptr<float>(),
+                               saved[5].data_ptr<float>(), gp[0].data_ptr<float>(), gp[1].data_ptr<float>(),
+                               gp[2].data_ptr<float>(), gp[3].data_ptr<float>(), fws.data_ptr(), ws.data_ptr(),
+                               (size_t)ws.numel(), (void*)st),
+              "pde_adi_backward");
+        return {gu, gp[0], gp[1], gp[2], gp[3], Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+    }
+};
+
+Tensor adi(const Tensor& u, const Tensor& ab, const Tensor& bb, const Tensor& asl, const Tensor& bsl, int64_t desc_addr,
+           int64_t ckpt_mode, int64_t ckpt_lo, int64_t ckpt_hi, double amax) {
+    // forward() runs with grad mode off: whether anything is kept for a backward is decided out here
+    const bool need_grad = at::GradMode::is_enabled() && (u.requires_grad() || ab.requires_grad() || bb.requires_grad() ||
+                                                          asl.requires_grad() || bsl.requires_grad());
+    return AdiFn::apply(u, ab, bb, asl, bsl, desc_addr, ckpt_mode, ckpt_lo, ckpt_hi, amax, need_grad);
+}
+
+
+// the union over the steps of the step-local plans (functional._AdiSmallFn.backward)
+void plan_steps(const float* kmax, int K, int sps, double amax, uint64_t mask[2]) {
+    mask[0] = mask[1] = 0;
+    for (int k = 0; k < K; ++k) {
+        uint64_t m[2];
+        plan_checkpoints(kmax + (size_t)k * sps, sps, amax, m);
+        mask[0] |= m[0];
+        mask[1] |= m[1];
+    }
+}
+
+Tensor as_f32(const Tensor& t) {
+    Tensor q = t.detach();
+    if (q.scalar_type() != at::kFloat) q = q.to(at::kFloat);
+    return q.contiguous();
+}
+
+std::vector<int64_t> states_shape(int64_t K, const Tensor& u) {
+    std::vector<int64_t> sh{K};
+    for (auto v : u.sizes()) sh.push_back(v);
+    return sh;
+}
+
+// ---- one layer with a channel operator between its steps, C <= 4, one launch per pass (functional._AdiSmallFn:
+// cifar10.py:84-112 "pre", SVHN.py:55-76 "post" with the skip blend) -----------------------------------------------
+struct SmallFn : public torch::autograd::Function<SmallFn> {
+    static Tensor forward(AutogradContext* ctx, const Tensor& u_in, const Tensor& ab, const Tensor& bb, const Tensor& asl,
+                          const Tensor& bsl, const Tensor& M, const std::optional<Tensor>& skip_opt, int64_t desc_addr, int64_t sps,
+                          int64_t mode, int64_t ckpt_mode, int64_t ckpt_lo, double amax, bool need_grad) {
+        const Tensor skip = skip_opt.has_value() ? *skip_opt : Tensor();
+        TORCH_CHECK(u_in.is_cuda() && ab.is_cuda() && bb.is_cuda() && asl.is_cuda() && bsl.is_cuda() && M.is_cuda() &&
+                        (!skip.defined() || skip.is_cuda()),
+                    "libpdecnn_hip operators need CUDA/HIP tensors (there is no CPU fallback)");
+        PdeAdiDesc d;
+        std::memcpy(&d, reinterpret_cast<const void*>(desc_addr), sizeof(d));
+        const int64_t B = u_in.size(0), C = u_in.size(1), N = u_in.size(2);
+        Tensor u = u_in.detach();
+        if (u.scalar_type() != at::kFloat && u.scalar_type() != at::kBFloat16) u = u.to(at::kFloat);
+        u = u.contiguous();
+        TORCH_CHECK(d.B == B && d.C == C && d.N == N && d.io_dtype == (u.scalar_type() == at::kBFloat16 ? PDE_IO_BF16 : PDE_IO_F32),
+                    "descriptor does not match the tensor");
+        const int64_t K = d.num_sweeps / sps;
+        Tensor p[4] = {as_chw(ab, C, N), as_chw(bb, C, N), as_chw(asl, C, N), as_chw(bsl, C, N)};
+        Tensor Mf = as_f32(M);
+        Tensor sw = skip.defined() ? as_f32(skip).reshape({1}) : Tensor();
+        const bool want_kmax = need_grad && ckpt_mode == 1;
+        c10::hip::HIPGuardMasqueradingAsCUDA guard(u.device());
+        hipStream_t st = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(u.device().index()).stream();
+        Tensor sws = bytes(pde_adi_steps_workspace_bytes(&d, (int32_t)sps), u);
+        Tensor kdev, ticket, states;
+        Slot* slot = nullptr;
+        if (want_kmax) {
+            kdev = at::empty({(int64_t)d.num_sweeps}, u.options().dtype(at::kFloat));
+            slot = acquire_slot(u.device().index());
+            ticket = slot_ticket(slot, d.num_sweeps);
+        }
+        if (need_grad) states = at::empty(states_shape(K, u), u.options());
+        Tensor y = at::empty_like(u);
+        check(pde_adi_small_forward(&d, (int32_t)sps, (int32_t)mode, u.data_ptr(), y.data_ptr(),
+                                    need_grad ? states.data_ptr() : nullptr, Mf.data_ptr<float>(),
+                                    sw.defined() ? sw.data_ptr<float>() : nullptr, p[0].data_ptr<float>(), p[1].data_ptr<float>(),
+                                    p[2].data_ptr<float>(), p[3].data_ptr<float>(), want_kmax ? kdev.data_ptr<float>() : nullptr,
+                                    slot ? slot->host : nullptr, slot ? (void*)slot->ev : nullptr, sws.data_ptr(),
+                                    (size_t)sws.numel(), (void*)st),
+              "pde_adi_small_forward");
+        if (need_grad) {
+            ctx->save_for_backward({u, Mf, sw, p[0], p[1], p[2], p[3]});
+            ctx->saved_data["states"] = states;
+            ctx->saved_data["sws"] = sws;
+            if (slot) {
+                ctx->saved_data["ticket"] = ticket;
+                ctx->saved_data["slot"] = (int64_t) reinterpret_cast<intptr_t>(slot);
+            }
+            ctx->saved_data["desc"] = std::string(reinterpret_cast<const char*>(&d), sizeof(d));
+            ctx->saved_data["cfg"] = std::vector<int64_t>{sps, mode, ckpt_mode, ckpt_lo, (int64_t)M.scalar_type(),
+                                                          skip.defined() ? (int64_t)skip.scalar_type() : -1};
+            ctx->saved_data["amax"] = amax;
+            ctx->saved_data["sh0"] = ab.sizes().vec();
+            ctx->saved_data["sh1"] = bb.sizes().vec();
+            ctx->saved_data["sh2"] = asl.sizes().vec();
+            ctx->saved_data["sh3"] = bsl.sizes().vec();
+            if (skip.defined()) ctx->saved_data["shs"] = skip.sizes().vec();
+        }
+        return y;
+    }
+
+    static variable_list backward(AutogradContext* ctx, variable_list grads) {
+        auto saved = ctx->get_saved_variables();
+        const Tensor &u = saved[0], &Mf = saved[1], &sw = saved[2];
+        PdeAdiDesc d;
+        std::memcpy(&d, ctx->saved_data["desc"].toStringRef().data(), sizeof(d));
+        auto cfg = ctx->saved_data["cfg"].toIntVector();
+        const int sps = (int)cfg[0], mode = (int)cfg[1], K = d.num_sweeps / sps;
+        uint64_t mask[2] = {(uint64_t)cfg[3], 0};
+        if (cfg[2] == 1) {
+            Slot* slot = reinterpret_cast<Slot*>((intptr_t)ctx->saved_data["slot"].toInt());
+            wait_event(slot->ev);
+            plan_steps(slot->host, K, sps, ctx->saved_data["amax"].toDouble(), mask);
+        }
+        c10::hip::HIPGuardMasqueradingAsCUDA guard(u.device());
+        hipStream_t st = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(u.device().index()).stream();
+        Tensor gy = grads[0];
+        if (gy.scalar_type() != u.scalar_type()) gy = gy.to(u.scalar_type());
+        gy = gy.contiguous();
+        Tensor gu = at::empty_like(gy);
+        static const char* const kShape[4] = {"sh0", "sh1", "sh2", "sh3"};
+        Tensor gp[4];
+        for (int i = 0; i < 4; ++i) gp[i] = at::empty(ctx->saved_data[kShape[i]].toIntVector(), saved[3 + i].options());
+        Tensor gM = at::empty_like(Mf);
+        Tensor gsw = sw.defined() ? at::empty({1}, Mf.options()) : Tensor();
+        Tensor ws = bytes(pde_adi_small_backward_workspace_bytes(&d, sps, popcount2(mask)), u);
+        Tensor states = ctx->saved_data["states"].toTensor(), sws = ctx->saved_data["sws"].toTensor();
+        check(pde_adi_small_backward(&d, sps, mode, gy.data_ptr(), u.data_ptr(), states.data_ptr(), Mf.data_ptr<float>(),
+                                     sw.defined() ? sw.data_ptr<float>() : nullptr, mask, gu.data_ptr(),
+                                     saved[3].data_ptr<float>(), saved[4].data_ptr<float>(), saved[5].data_ptr<float>(),
+                                     saved[6].data_ptr<float>(), gp[0].data_ptr<float>(), gp[1].data_ptr<float>(),
+                                     gp[2].data_ptr<float>(), gp[3].data_ptr<float>(), gM.data_ptr<float>(),
+                                     gsw.defined() ? gsw.data_ptr<float>() : nullptr, sws.data_ptr(), ws.data_ptr(),
+                                     (size_t)ws.numel(), (void*)st),
+              "pde_adi_small_backward");
+        if ((int64_t)gM.scalar_type() != cfg[4]) gM = gM.to((at::ScalarType)cfg[4]);
+        if (gsw.defined()) {
+            if ((int64_t)gsw.scalar_type() != cfg[5]) gsw = gsw.to((at::ScalarType)cfg[5]);
+            gsw = gsw.reshape(ctx->saved_data["shs"].toIntVector());
+        }
+        return {gu, gp[0], gp[1], gp[2], gp[3], gM, gsw, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+    }
+};
+
+Tensor small(const Tensor& u, const Tensor& ab, const Tensor& bb, const Tensor& asl, const Tensor& bsl, const Tensor& M,
+             const std::optional<Tensor>& skip, int64_t desc_addr, int64_t sps, int64_t mode, int64_t ckpt_mode, int64_t ckpt_lo,
+             double amax) {
+    const Tensor sk = (skip.has_value() && skip->defined()) ? *skip : Tensor();
+    const std::optional<Tensor> sko = sk.defined() ? std::optional<Tensor>(sk) : std::nullopt;
+    const bool need_grad = at::GradMode::is_enabled() &&
+                           (u.requires_grad() || ab.requires_grad() || bb.requires_grad() || asl.requires_grad() ||
+                            bsl.requires_grad() || M.requires_grad() || (sk.defined() && sk.requires_grad()));
+    return SmallFn::apply(u, ab, bb, asl, bsl, M, sko, desc_addr, sps, mode, ckpt_mode, ckpt_lo, amax, need_grad);
+}
+
+// ---- several mixing-first layers on the SAME input, one launch per pass (functional._AdiMultiFn: cifar10.py:272-280,
+// cifar_2version.py:287-288).  Returns (sum_i w_i y_i, y_1 .. y_L[, s_1 .. s_L]) ----------------------------------------
+struct MultiFn : public torch::autograd::Function<MultiFn> {
+    static variable_list forward(AutogradContext* ctx, const Tensor& u_in, const std::optional<Tensor>& w_opt, at::TensorList flat,
+                                 std::vector<int64_t> desc_addrs, int64_t sps, bool want_sums, int64_t ckpt_mode,
+                                 std::vector<int64_t> masks, double amax, bool need_grad) {
+        const int nl = (int)desc_addrs.size();
+        const Tensor weights = w_opt.has_value() ? *w_opt : Tensor();
+        TORCH_CHECK(nl >= 1 && (int)flat.size() == 5 * nl, "adi_diffuse_multi: five tensors per layer");
+        TORCH_CHECK(u_in.is_cuda() && (!weights.defined() || weights.is_cuda()),
+                    "libpdecnn_hip operators need CUDA/HIP tensors (there is no CPU fallback)");
+        for (const auto& t : flat) TORCH_CHECK(t.is_cuda(), "libpdecnn_hip operators need CUDA/HIP tensors (there is no CPU fallback)");
+        const int64_t B = u_in.size(0), C = u_in.size(1), N = u_in.size(2);
+        Tensor u = u_in.detach();
+        if (u.scalar_type() != at::kFloat && u.scalar_type() != at::kBFloat16) u = u.to(at::kFloat);
+        u = u.contiguous();
+        const bool want_kmax = need_grad && ckpt_mode == 1;
+        ctx->set_materialize_grads(false);
+        Tensor wdev = weights.defined() ? as_f32(weights) : Tensor();
+        c10::hip::HIPGuardMasqueradingAsCUDA guard(u.device());
+        hipStream_t st = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(u.device().index()).stream();
+
+        std::vector<PdeAdiDesc> descs(nl);
+        std::vector<PdeSmallLayer> arr(nl);
+        std::vector<Tensor> save{u, wdev}, hold, states_v, sums_v, tickets;
+        std::vector<int64_t> slots, meta;
+        std::string shapes;                                   // the parameter shapes, for the gradients
+        for (int i = 0; i < nl; ++i) {
+            PdeAdiDesc& d = descs[i];
+            std::memcpy(&d, reinterpret_cast<const void*>(desc_addrs[i]), sizeof(d));
+            TORCH_CHECK(d.B == B && d.C == C && d.N == N && d.io_dtype == (u.scalar_type() == at::kBFloat16 ? PDE_IO_BF16 : PDE_IO_F32),
+                        "descriptor does not match the tensor");
+            const int64_t K = d.num_sweeps / sps;
+            Tensor p[4];
+            for (int j = 0; j < 4; ++j) p[j] = as_chw(flat[5 * i + j], C, N);
+            Tensor Mf = as_f32(flat[5 * i + 4]);
+            Tensor sws = bytes(pde_adi_steps_workspace_bytes(&d, (int32_t)sps), u);
+            Tensor states = at::empty(states_shape(K, u), u.options());
+            Tensor kdev;
+            Slot* slot = nullptr;
+            if (want_kmax) {
+                kdev = at::empty({(int64_t)d.num_sweeps}, u.options().dtype(at::kFloat));
+                slot = acquire_slot(u.device().index());
+                tickets.push_back(slot_ticket(slot, d.num_sweeps));
+                hold.push_back(kdev);
+            }
+            slots.push_back((int64_t) reinterpret_cast<intptr_t>(slot));
+            Tensor psum = want_sums ? at::empty({B, C}, u.options().dtype(at::kFloat)) : Tensor();
+            PdeSmallLayer& a = arr[i];
+            std::memset(&a, 0, sizeof(a));
+            a.desc = &d;
+            a.sweeps_per_step = (int32_t)sps;
+            a.mode = 1;
+            a.M = Mf.data_ptr<float>();
+            a.alpha_base = p[0].data_ptr<float>();
+            a.beta_base = p[1].data_ptr<float>();
+            a.alpha_slope = p[2].data_ptr<float>();
+            a.beta_slope = p[3].data_ptr<float>();
+            a.weight = 0.f;
+            a.weight_ptr = wdev.defined() ? wdev.data_ptr<float>() + i : nullptr;
+            a.states = states.data_ptr();
+            a.steps_workspace = sws.data_ptr();
+            a.steps_workspace_bytes = (size_t)sws.numel();
+            a.kappa_max = want_kmax ? kdev.data_ptr<float>() : nullptr;
+            a.kappa_max_host = slot ? slot->host : nullptr;
+            a.plane_sums = psum.defined() ? psum.data_ptr<float>() : nullptr;
+            for (int j = 0; j < 4; ++j) save.push_back(p[j]);
+            save.push_back(Mf);
+            hold.push_back(sws);
+            states_v.push_back(states);
+            sums_v.push_back(psum);
+            meta.push_back((int64_t)flat[5 * i + 4].scalar_type());
+        }
+        Tensor out = at::empty_like(u);
+        Slot* last = want_kmax ? reinterpret_cast<Slot*>((intptr_t)slots.back()) : nullptr;   // recorded behind the last layer's copy
+        check(pde_adi_multi_forward(nl, arr.data(), u.data_ptr(), out.data_ptr(), last ? (void*)last->ev : nullptr, (void*)st),
+              "pde_adi_multi_forward");
+        if (need_grad) {
+            ctx->save_for_backward(save);
+            ctx->saved_data["hold"] = hold;
+            ctx->saved_data["states"] = states_v;
+            if (want_kmax) ctx->saved_data["tickets"] = tickets;
+            ctx->saved_data["slots"] = slots;
+            ctx->saved_data["descs"] = std::string(reinterpret_cast<const char*>(descs.data()), sizeof(PdeAdiDesc) * nl);
+            ctx->saved_data["cfg"] = std::vector<int64_t>{nl, sps, want_sums ? 1 : 0, ckpt_mode,
+                                                          weights.defined() ? 1 : 0};
+            ctx->saved_data["masks"] = masks;
+            ctx->saved_data["mdt"] = meta;
+            ctx->saved_data["amax"] = amax;
+            for (int i = 0; i < 4 * nl; ++i)
+                ctx->saved_data["sh" + std::to_string(i)] = flat[5 * (i / 4) + (i % 4)].sizes().vec();
+        }
+        variable_list res{out};
+        for (int i = 0; i < nl; ++i) res.push_back(states_v[i].select(0, states_v[i].size(0) - 1));   // the last sweep output of every layer
+        if (want_sums)
+            for (int i = 0; i < nl; ++i) res.push_back(sums_v[i]);
+        return res;
+    }
+
+    static variable_list backward(AutogradContext* ctx, variable_list grads) {
+        auto saved = ctx->get_saved_variables();
+        auto cfg = ctx->saved_data["cfg"].toIntVector();
+        const int nl = (int)cfg[0], sps = (int)cfg[1];
+        const bool want_sums = cfg[2] != 0, has_w = cfg[4] != 0;
+        const Tensor &u = saved[0], &wdev = saved[1];
+        std::vector<PdeAdiDesc> descs(nl);
+        std::memcpy(descs.data(), ctx->saved_data["descs"].toStringRef().data(), sizeof(PdeAdiDesc) * nl);
+        auto slots = ctx->saved_data["slots"].toIntVector();
+        auto masks = ctx->saved_data["masks"].toIntVector();
+        auto mdt = ctx->saved_data["mdt"].toIntVector();
+        auto states_v = ctx->saved_data["states"].toTensorVector();
+        auto hold = ctx->saved_data["hold"].toTensorVector();
+        const double amax = ctx->saved_data["amax"].toDouble();
+        if (cfg[3] == 1) wait_event(reinterpret_cast<Slot*>((intptr_t)slots.back())->ev);
+        c10::hip::HIPGuardMasqueradingAsCUDA guard(u.device());
+        hipStream_t st = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(u.device().index()).stream();
+
+        Tensor gout = grads[0];
+        if (gout.defined()) {
+            if (gout.scalar_type() != u.scalar_type()) gout = gout.to(u.scalar_type());
+            gout = gout.contiguous();
+        }
+        std::vector<PdeSmallLayer> arr(nl);
+        std::vector<uint64_t> mk(2 * nl);
+        std::vector<Tensor> keep;
+        variable_list res(2 + 5 * nl + 7);                    // u, weights, five per layer, the seven non-tensor arguments
+        std::vector<Tensor> gws;
+        bool any_in = gout.defined();
+        const int kmax_stride = cfg[3] == 1 ? 2 : 1;          // hold: [kdev, sws] per layer with coefficient maxima, else [sws]
+        for (int i = 0; i < nl; ++i) {
+            PdeAdiDesc& d = descs[i];
+            const int K = d.num_sweeps / sps;
+            uint64_t* m = &mk[2 * i];
+            m[0] = m[1] = 0;
+            if (cfg[3] == 1) plan_steps(reinterpret_cast<Slot*>((intptr_t)slots[i])->host, K, sps, amax, m);
+            else m[0] = (uint64_t)masks[i];
+            const Tensor* p = &saved[2 + 5 * i];
+            const Tensor& Mf = saved[2 + 5 * i + 4];
+            Tensor ws = bytes(pde_adi_small_backward_workspace_bytes(&d, sps, popcount2(m)), u);
+            Tensor gp[4];
+            for (int j = 0; j < 4; ++j) gp[j] = at::empty(ctx->saved_data["sh" + std::to_string(4 * i + j)].toIntVector(), p[j].options());
+            Tensor gM = at::empty_like(Mf);
+            Tensor gw = at::empty({1}, Mf.options());
+            Tensor gyi = grads[1 + i], gsi = want_sums ? grads[1 + nl + i] : Tensor();
+            if (gyi.defined()) {
+                if (gyi.scalar_type() != u.scalar_type()) gyi = gyi.to(u.scalar_type());
+                gyi = gyi.contiguous();
+            }
+            if (gsi.defined()) {
+                if (gsi.scalar_type() != at::kFloat) gsi = gsi.to(at::kFloat);
+                gsi = gsi.contiguous();
+            }
+            any_in = any_in || gyi.defined() || gsi.defined();
+            const Tensor& sws = hold[kmax_stride * i + (kmax_stride - 1)];
+            PdeSmallLayer& a = arr[i];
+            std::memset(&a, 0, sizeof(a));
+            a.desc = &d;
+            a.sweeps_per_step = sps;
+            a.mode = 1;
+            a.M = Mf.data_ptr<float>();
+            a.alpha_base = p[0].data_ptr<float>();
+            a.beta_base = p[1].data_ptr<float>();
+            a.alpha_slope = p[2].data_ptr<float>();
+            a.beta_slope = p[3].data_ptr<float>();
+            a.weight = 0.f;
+            a.weight_ptr = wdev.defined() ? wdev.data_ptr<float>() + i : nullptr;
+            a.states = states_v[i].data_ptr();
+            a.steps_workspace = sws.data_ptr();
+            a.steps_workspace_bytes = (size_t)sws.numel();
+            a.gys = gyi.defined() ? gyi.data_ptr() : nullptr;
+            a.g_plane_sums = gsi.defined() ? gsi.data_ptr<float>() : nullptr;
+            a.ckpt_mask = m;
+            a.g_alpha_base = gp[0].data_ptr<float>();
+            a.g_beta_base = gp[1].data_ptr<float>();
+            a.g_alpha_slope = gp[2].data_ptr<float>();
+            a.g_beta_slope = gp[3].data_ptr<float>();
+            a.gM = gM.data_ptr<float>();
+            a.g_weight = gw.data_ptr<float>();
+            a.workspace = ws.data_ptr();
+            a.workspace_bytes = (size_t)ws.numel();
+            keep.push_back(ws);
+            keep.push_back(gyi);
+            keep.push_back(gsi);
+            for (int j = 0; j < 4; ++j) res[2 + 5 * i + j] = gp[j];
+            res[2 + 5 * i + 4] = gM;                                        // converted to the operator's type behind the launch
+            gws.push_back(gw);
+        }
+        TORCH_CHECK(any_in, "adi_diffuse_multi: no incoming gradient");
+        Tensor gu = at::empty_like(u);
+        check(pde_adi_multi_backward(nl, arr.data(), gout.defined() ? gout.data_ptr() : nullptr, u.data_ptr(), gu.data_ptr(),
+                                     (void*)st),
+              "pde_adi_multi_backward");
+        for (int i = 0; i < nl; ++i)
+            if ((int64_t)res[2 + 5 * i + 4].scalar_type() != mdt[i]) res[2 + 5 * i + 4] = res[2 + 5 * i + 4].to((at::ScalarType)mdt[i]);
+        res[0] = gu;
+        if (has_w) res[1] = at::cat(gws);
+        return res;
+    }
+};
+
+variable_list multi(const Tensor& u, const std::optional<Tensor>& weights, std::vector<Tensor> flat,
+                    std::vector<int64_t> desc_addrs, int64_t sps, bool want_sums, int64_t ckpt_mode, std::vector<int64_t> masks,
+                    double amax) {
+    const Tensor w = (weights.has_value() && weights->defined()) ? *weights : Tensor();
+    const std::optional<Tensor> wo = w.defined() ? std::optional<Tensor>(w) : std::nullopt;
+    bool need_grad = u.requires_grad() || (w.defined() && w.requires_grad());
+    for (const auto& t : flat) need_grad = need_grad || t.requires_grad();
+    need_grad = need_grad && at::GradMode::is_enabled();
+    return MultiFn::apply(u, wo, at::TensorList(flat), desc_addrs, sps, want_sums, ckpt_mode, masks, amax, need_grad);
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+    m.doc() = "native host path of the launch-bound PDE-layer calls (torch C++ autograd over the C ABI of pdecnn.h)";
+    m.def("adi", &adi, "functional.adi_diffuse without the interpreter: one implicit diffusion layer call",
+          py::arg("u"), py::arg("alpha_base"), py::arg("beta_base"), py::arg("alpha_time_coeff"), py::arg("beta_time_coeff"),
+          py::arg("desc_addr"), py::arg("ckpt_mode"), py::arg("ckpt_lo"), py::arg("ckpt_hi"), py::arg("amax"));
+    m.def("small", &small, "functional.adi_diffuse_small: one layer with a channel operator, C <= 4, one launch per pass",
+          py::arg("u"), py::arg("alpha_base"), py::arg("beta_base"), py::arg("alpha_time_coeff"), py::arg("beta_time_coeff"),
+          py::arg("M"), py::arg("skip_weight"), py::arg("desc_addr"), py::arg("sweeps_per_step"), py::arg("mode"),
+          py::arg("ckpt_mode"), py::arg("ckpt_lo"), py::arg("amax"));
+    m.def("multi", &multi, "functional.adi_diffuse_multi: layers that share an input, one launch per pass",
+          py::arg("u"), py::arg("weights"), py::arg("flat"), py::arg("desc_addrs"), py::arg("sweeps_per_step"),
+          py::arg("want_sums"), py::arg("ckpt_mode"), py::arg("masks"), py::arg("amax"));
+    m.def("abi_version", []() { return std::string(pde_version()); });
+}

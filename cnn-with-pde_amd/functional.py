@@ -102,6 +102,7 @@ def _io_dtype(t: torch.Tensor) -> int:
 
 
 _desc_cache = {}
+_M64 = (1 << 64) - 1
 
 
 def _make_desc(B, Cc, N, io, sweeps: Sequence[Sweep], smooth3, clamp_max, eps) -> L.PdeAdiDesc:
@@ -694,8 +695,25 @@ def adi_diffuse_multi(u, layers, weights=None, plane_sums=False, checkpoints="au
         flat += [ly["alpha_base"], ly["beta_base"], ly["alpha_time_coeff"], ly["beta_time_coeff"], ly["M"]]
     if isinstance(checkpoints, list):
         checkpoints = tuple(checkpoints)
-    res = _AdiMultiFn.apply(u, weights, specs, bool(plane_sums), checkpoints, *flat)
     nl = len(layers)
+    H = L.host_ext()
+    if H is not None and u.dim() == 4 and u.is_cuda and u.shape[0] > 0 and len({len(sp[0][0]) for sp in specs}) == 1:
+        # the native host path (csrc/host_ext.cpp): the same call of the C ABI from a C++ autograd node
+        if checkpoints == "auto":
+            mode, masks = 1, []
+        else:
+            masks = [int(checkpoints)] * nl if not isinstance(checkpoints, tuple) else [int(c) for c in checkpoints]
+            if len(masks) != nl:
+                raise L.PdeError(f"adi_diffuse_multi: {len(masks)} checkpoint masks for {nl} layers")
+            mode = 0
+        B, Cc, N, _ = u.shape
+        io = L.PDE_IO_BF16 if u.dtype == torch.bfloat16 else L.PDE_IO_F32
+        addrs = [C.addressof(_make_desc(B, Cc, N, io, st.flat, sm, cm, ep)) for st, sm, cm, ep in specs]
+        res = H.multi(u, weights, flat, addrs, len(specs[0][0][0]), bool(plane_sums), mode, masks, CKPT_AMAX)
+        if plane_sums:
+            return res[0], list(res[1:1 + nl]), list(res[1 + nl:])
+        return res[0], list(res[1:])
+    res = _AdiMultiFn.apply(u, weights, specs, bool(plane_sums), checkpoints, *flat)
     if plane_sums:
         return res[0], list(res[1:1 + nl]), list(res[1 + nl:])
     return res[0], list(res[1:])
@@ -731,6 +749,16 @@ def adi_diffuse_small(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coef
     if mode not in ("pre", "post"):
         raise ValueError(mode)
     steps = _as_schedule(steps)
+    if kmax_sink is None and (checkpoints == "auto" or isinstance(checkpoints, int)) and u.shape[0] > 0:
+        H = L.host_ext()
+        if H is not None and u.dim() == 4 and u.is_cuda:
+            # the native host path (csrc/host_ext.cpp): the same call of the C ABI from a C++ autograd node
+            B, Cc, N, _ = u.shape
+            d = _make_desc(B, Cc, N, L.PDE_IO_BF16 if u.dtype == torch.bfloat16 else L.PDE_IO_F32, steps.flat, smooth3,
+                           clamp_max, eps)
+            return H.small(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff, M, skip_weight, C.addressof(d),
+                           len(steps[0]), 1 if mode == "pre" else 2, 1 if checkpoints == "auto" else 0,
+                           0 if checkpoints == "auto" else int(checkpoints), CKPT_AMAX)
     return _AdiSmallFn.apply(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff, M, skip_weight, steps, mode,
                              bool(smooth3), clamp_max, float(eps), checkpoints, kmax_sink)
 
@@ -792,9 +820,25 @@ def adi_diffuse(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff, swe
     """
     if u.shape[0] == 0:
         return _empty_passthrough(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff)
+    if not isinstance(sweeps, tuple):
+        sweeps = tuple(sweeps)
+    if kmax_sink is None and (checkpoints == "auto" or isinstance(checkpoints, int)):
+        H = L.host_ext()
+        if H is not None and u.dim() == 4 and u.is_cuda and u.dtype in (torch.float32, torch.bfloat16, torch.float16,
+                                                                        torch.float64):
+            # the native host path (csrc/host_ext.cpp): the same two calls of the C ABI from a C++ autograd node
+            B, Cc, N, _ = u.shape
+            d = _make_desc(B, Cc, N, L.PDE_IO_BF16 if u.dtype == torch.bfloat16 else L.PDE_IO_F32, sweeps, smooth3,
+                           clamp_max, eps)
+            if checkpoints == "auto":
+                mode, lo, hi = 1, 0, 0
+            else:
+                bits = int(checkpoints)
+                mode, lo, hi = 0, bits & _M64, (bits >> 64) & _M64
+                lo, hi = (lo - (1 << 64) if lo >> 63 else lo), (hi - (1 << 64) if hi >> 63 else hi)
+            return H.adi(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff, C.addressof(d), mode, lo, hi, CKPT_AMAX)
     return _AdiFn.apply(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff,
-                        sweeps if isinstance(sweeps, tuple) else tuple(sweeps),
-                        bool(smooth3), clamp_max, float(eps), checkpoints, kmax_sink)
+                        sweeps, bool(smooth3), clamp_max, float(eps), checkpoints, kmax_sink)
 
 
 # --------------------------------------------------------------------------- channel mixing

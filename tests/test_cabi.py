@@ -63,3 +63,11 @@ def test_argument_validation_without_gpu():
     assert lib.pde_channel_mix_forward(0, 3, 16, 0, None, None, None, None) == -1
     assert lib.pde_explicit5_forward(1, 1, 8, 6, 0, None, None, None, 0.01, 1e-6, 0.15, 0.1, 1, None, None, None) == -1
     assert lib.pde_version().startswith(b"pdecnn-hip")
+
+
+def test_native_host_extension_loads_and_is_linked_against_the_library():
+    """csrc/host_ext.cpp: host glue over the same C ABI; importing it runs no kernel."""
+    from cnn_with_pde_amd import _lib as L
+    H = L.host_ext()
+    assert H is not None and callable(H.adi)
+    assert H.abi_version() == L.load().pde_version().decode()
