@@ -165,6 +165,7 @@ def host_ext():
             spec = importlib.util.spec_from_file_location("_pdecnn_host", HOST_EXT_PATH)
             mod = importlib.util.module_from_spec(spec)
             spec.loader.exec_module(mod)
+            mod.set_error_class(PdeError)
             _host = mod
     return _host or None
 

@@ -15,6 +15,8 @@
 
 #include <atomic>
 #include <cstring>
+#include <stdexcept>
+#include <string>
 #include <memory>
 #include <mutex>
 #include <vector>
@@ -30,7 +32,9 @@ using torch::autograd::variable_list;
 const char* err_text(int rc) {
     switch (rc) {
         case -1: return "PDE_E_BADARG (null pointer, bad dimension or enum)";
-        case -2: return "PDE_E_UNSUPPORTED_N";
+        case -2:
+            return "PDE_E_UNSUPPORTED_N (line length outside [2, 128], or a per-step / one-launch entry point at a line length "
+                   "without fused kernels: those exist for multiples of 4 in [8, 32])";
         case -3: return "PDE_E_TOO_MANY_SWEEPS";
         case -4: return "PDE_E_LAUNCH (HIP launch failed)";
         case -5: return "PDE_E_WORKSPACE (workspace too small or misaligned)";
@@ -38,8 +42,19 @@ const char* err_text(int rc) {
     return "unknown error";
 }
 
+// A failed call of the C ABI: reaches Python as _lib.PdeError (a RuntimeError), like the ctypes path's
+struct PdeFailure : public std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+PyObject* g_error_class = nullptr;
+
+#define PDE_REQUIRE(cond, ...)                                  \
+    do {                                                        \
+        if (!(cond)) throw PdeFailure(c10::str(__VA_ARGS__));   \
+    } while (0)
+
 void check(int rc, const char* what) {
-    TORCH_CHECK(rc == 0, what, " failed: ", err_text(rc), " (", rc, ")");
+    if (rc != 0) throw PdeFailure(std::string(what) + " failed: " + err_text(rc));
 }
 
 // ---- the way the per-sweep coefficient maxima reach the host: pinned slots, one event each -------------------------------
@@ -150,7 +165,7 @@ int popcount2(const uint64_t m[2]) { return __builtin_popcountll(m[0]) + __built
 Tensor as_chw(const Tensor& p, int64_t C, int64_t N) {
     Tensor q = p.detach();
     if (q.dim() == 2) q = q.unsqueeze(0);
-    TORCH_CHECK(q.dim() == 3 && q.size(0) == C && q.size(1) == N && q.size(2) == N, "coefficient of shape ", p.sizes(),
+    PDE_REQUIRE(q.dim() == 3 && q.size(0) == C && q.size(1) == N && q.size(2) == N, "coefficient of shape ", p.sizes(),
                 " does not match (", C, ",", N, ",", N, ")");
     if (q.scalar_type() != at::kFloat) q = q.to(at::kFloat);
     return q.contiguous();
@@ -165,16 +180,16 @@ struct AdiFn : public torch::autograd::Function<AdiFn> {
     static Tensor forward(AutogradContext* ctx, const Tensor& u_in, const Tensor& ab, const Tensor& bb, const Tensor& asl,
                           const Tensor& bsl, int64_t desc_addr, int64_t ckpt_mode, int64_t ckpt_lo, int64_t ckpt_hi,
                           double amax, bool need_grad) {
-        TORCH_CHECK(u_in.is_cuda() && ab.is_cuda() && bb.is_cuda() && asl.is_cuda() && bsl.is_cuda(),
+        PDE_REQUIRE(u_in.is_cuda() && ab.is_cuda() && bb.is_cuda() && asl.is_cuda() && bsl.is_cuda(),
                     "libpdecnn_hip operators need CUDA/HIP tensors (there is no CPU fallback)");
-        TORCH_CHECK(u_in.dim() == 4 && u_in.size(2) == u_in.size(3), "expected (B,C,N,N), got ", u_in.sizes());
+        PDE_REQUIRE(u_in.dim() == 4 && u_in.size(2) == u_in.size(3), "expected (B,C,N,N), got ", u_in.sizes());
         PdeAdiDesc d;
         std::memcpy(&d, reinterpret_cast<const void*>(desc_addr), sizeof(d));
         const int64_t B = u_in.size(0), C = u_in.size(1), N = u_in.size(2);
         Tensor u = u_in.detach();
         if (u.scalar_type() != at::kFloat && u.scalar_type() != at::kBFloat16) u = u.to(at::kFloat);
         u = u.contiguous();
-        TORCH_CHECK(d.B == B && d.C == C && d.N == N && d.io_dtype == (u.scalar_type() == at::kBFloat16 ? PDE_IO_BF16 : PDE_IO_F32),
+        PDE_REQUIRE(d.B == B && d.C == C && d.N == N && d.io_dtype == (u.scalar_type() == at::kBFloat16 ? PDE_IO_BF16 : PDE_IO_F32),
                     "descriptor does not match the tensor");
         Tensor p[4] = {as_chw(ab, C, N), as_chw(bb, C, N), as_chw(asl, C, N), as_chw(bsl, C, N)};
         const bool want_kmax = need_grad && ckpt_mode == 1;
@@ -226,7 +241,7 @@ struct AdiFn : public torch::autograd::Function<AdiFn> {
             plan_checkpoints(slot->host, d.num_sweeps, ctx->saved_data["amax"].toDouble(), mask);
         }
         const bool any = (mask[0] | mask[1]) != 0;
-        TORCH_CHECK(!any || u.defined(), "a checkpoint plan needs the layer input, which was not kept");
+        PDE_REQUIRE(!any || u.defined(), "a checkpoint plan needs the layer input, which was not kept");
         c10::hip::HIPGuardMasqueradingAsCUDA guard(y.device());                 // autograd's worker thread: set the device, fetch the stream here
         hipStream_t st = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(y.device().index()).stream();
         Tensor gy = grads[0];
@@ -287,7 +302,7 @@ struct SmallFn : public torch::autograd::Function<SmallFn> {
                           const Tensor& bsl, const Tensor& M, const std::optional<Tensor>& skip_opt, int64_t desc_addr, int64_t sps,
                           int64_t mode, int64_t ckpt_mode, int64_t ckpt_lo, double amax, bool need_grad) {
         const Tensor skip = skip_opt.has_value() ? *skip_opt : Tensor();
-        TORCH_CHECK(u_in.is_cuda() && ab.is_cuda() && bb.is_cuda() && asl.is_cuda() && bsl.is_cuda() && M.is_cuda() &&
+        PDE_REQUIRE(u_in.is_cuda() && ab.is_cuda() && bb.is_cuda() && asl.is_cuda() && bsl.is_cuda() && M.is_cuda() &&
                         (!skip.defined() || skip.is_cuda()),
                     "libpdecnn_hip operators need CUDA/HIP tensors (there is no CPU fallback)");
         PdeAdiDesc d;
@@ -296,7 +311,7 @@ struct SmallFn : public torch::autograd::Function<SmallFn> {
         Tensor u = u_in.detach();
         if (u.scalar_type() != at::kFloat && u.scalar_type() != at::kBFloat16) u = u.to(at::kFloat);
         u = u.contiguous();
-        TORCH_CHECK(d.B == B && d.C == C && d.N == N && d.io_dtype == (u.scalar_type() == at::kBFloat16 ? PDE_IO_BF16 : PDE_IO_F32),
+        PDE_REQUIRE(d.B == B && d.C == C && d.N == N && d.io_dtype == (u.scalar_type() == at::kBFloat16 ? PDE_IO_BF16 : PDE_IO_F32),
                     "descriptor does not match the tensor");
         const int64_t K = d.num_sweeps / sps;
         Tensor p[4] = {as_chw(ab, C, N), as_chw(bb, C, N), as_chw(asl, C, N), as_chw(bsl, C, N)};
@@ -405,10 +420,10 @@ struct MultiFn : public torch::autograd::Function<MultiFn> {
                                  std::vector<int64_t> masks, double amax, bool need_grad) {
         const int nl = (int)desc_addrs.size();
         const Tensor weights = w_opt.has_value() ? *w_opt : Tensor();
-        TORCH_CHECK(nl >= 1 && (int)flat.size() == 5 * nl, "adi_diffuse_multi: five tensors per layer");
-        TORCH_CHECK(u_in.is_cuda() && (!weights.defined() || weights.is_cuda()),
+        PDE_REQUIRE(nl >= 1 && (int)flat.size() == 5 * nl, "adi_diffuse_multi: five tensors per layer");
+        PDE_REQUIRE(u_in.is_cuda() && (!weights.defined() || weights.is_cuda()),
                     "libpdecnn_hip operators need CUDA/HIP tensors (there is no CPU fallback)");
-        for (const auto& t : flat) TORCH_CHECK(t.is_cuda(), "libpdecnn_hip operators need CUDA/HIP tensors (there is no CPU fallback)");
+        for (const auto& t : flat) PDE_REQUIRE(t.is_cuda(), "libpdecnn_hip operators need CUDA/HIP tensors (there is no CPU fallback)");
         const int64_t B = u_in.size(0), C = u_in.size(1), N = u_in.size(2);
         Tensor u = u_in.detach();
         if (u.scalar_type() != at::kFloat && u.scalar_type() != at::kBFloat16) u = u.to(at::kFloat);
@@ -427,7 +442,7 @@ struct MultiFn : public torch::autograd::Function<MultiFn> {
         for (int i = 0; i < nl; ++i) {
             PdeAdiDesc& d = descs[i];
             std::memcpy(&d, reinterpret_cast<const void*>(desc_addrs[i]), sizeof(d));
-            TORCH_CHECK(d.B == B && d.C == C && d.N == N && d.io_dtype == (u.scalar_type() == at::kBFloat16 ? PDE_IO_BF16 : PDE_IO_F32),
+            PDE_REQUIRE(d.B == B && d.C == C && d.N == N && d.io_dtype == (u.scalar_type() == at::kBFloat16 ? PDE_IO_BF16 : PDE_IO_F32),
                         "descriptor does not match the tensor");
             const int64_t K = d.num_sweeps / sps;
             Tensor p[4];
@@ -584,7 +599,7 @@ struct MultiFn : public torch::autograd::Function<MultiFn> {
             res[2 + 5 * i + 4] = gM;                                        // converted to the operator's type behind the launch
             gws.push_back(gw);
         }
-        TORCH_CHECK(any_in, "adi_diffuse_multi: no incoming gradient");
+        PDE_REQUIRE(any_in, "adi_diffuse_multi: no incoming gradient");
         Tensor gu = at::empty_like(u);
         check(pde_adi_multi_backward(nl, arr.data(), gout.defined() ? gout.data_ptr() : nullptr, u.data_ptr(), gu.data_ptr(),
                                      (void*)st),
@@ -622,5 +637,16 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("multi", &multi, "functional.adi_diffuse_multi: layers that share an input, one launch per pass",
           py::arg("u"), py::arg("weights"), py::arg("flat"), py::arg("desc_addrs"), py::arg("sweeps_per_step"),
           py::arg("want_sums"), py::arg("ckpt_mode"), py::arg("masks"), py::arg("amax"));
+    m.def("set_error_class", [](py::object cls) {
+        Py_XDECREF(g_error_class);
+        g_error_class = cls.release().ptr();
+    }, "the Python exception class failed calls of the C ABI raise (_lib.PdeError)");
+    py::register_exception_translator([](std::exception_ptr p) {
+        try {
+            if (p) std::rethrow_exception(p);
+        } catch (const PdeFailure& e) {
+            PyErr_SetString(g_error_class ? g_error_class : PyExc_RuntimeError, e.what());
+        }
+    });
     m.def("abi_version", []() { return std::string(pde_version()); });
 }
