@@ -111,10 +111,11 @@ SIGNATURES = {
     "pde_jacobi_backward_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "pde_jacobi_backward": (C.c_int, [_i32, _i32, _i32, _i32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _sz, _vp]),
     "pde_sym_layer_supported": (C.c_int, [_i32, _i32]),
+    "pde_sym_layer_workspace_bytes": (_sz, [_i32, _i32]),
     "pde_sym_layer_forward": (C.c_int, [_i32, _i32, _i32, _i32, _fp, _fp, _fp, _fp, _fp, _fp, _f32, _f32, _fp, _f32,
-                                        _fp, _fp, _fp, _fp, _fp, _vp]),
+                                        _fp, _fp, _fp, _fp, _fp, _vp, _sz, _vp]),
     "pde_sym_layer_backward": (C.c_int, [_i32, _i32, _i32, _i32, _fp, _f32, _fp, _fp, _fp, _fp, _fp, _fp, _fp,
-                                         _fp, _fp, _fp, _fp, _fp, _vp]),
+                                         _fp, _fp, _fp, _fp, _fp, _vp, _sz, _vp]),
     "pde_timing_enable": (C.c_int, [_i32]),
     "pde_timing_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                   C.POINTER(C.c_int64)]),

@@ -37,7 +37,8 @@ constexpr int kRhCols = 16;              // output features per strip workgroup:
 // contraction slab of a strip workgroup with R row blocks per wave: 64 / R, so that the X slab (128 R rows) stays ~35 KB
 // and two of them (double buffering: one barrier per slab) fit beside each other whatever the batch
 template <int R> struct RhSlab { static constexpr int BK = 64 / R, LDA = BK + 4; };
-constexpr int kRhLdN = 20;               // LDS row stride of a [BK][16] slab (NN operand): the four k-quarters hit disjoint banks
+constexpr int kRhLdN = 20;
+constexpr int kRhRows32 = 128;             // batch rows of a 32-column strip workgroup (four waves x 32)               // LDS row stride of a [BK][16] slab (NN operand): the four k-quarters hit disjoint banks
 
 enum { kActIdentity = 0, kActRelu = 1, kActTanh = 2 };
 
@@ -392,6 +393,250 @@ __global__ __launch_bounds__(kRhStripThreads) void rh_bwd_strip_kernel(RhBwdArgs
         }
 }
 
+// ---- batches up to 128 rows: 32-column strips, the contraction split over workgroups ----------------------------------
+// One 16-column strip workgroup per CU (D / 16 = 192 of them at D = 3072) leaves the matrix cores waiting: for its K rows
+// from HBM (a slab of MFMAs does not cover that latency and there is no second workgroup on the CU to fill in) and for
+// LDS (a 16 x 16 x 4 MFMA consumes 512 B of operands per 32 cycles).  Here a workgroup of four waves owns 128 rows x 32
+// columns on v_mfma_f32_32x32x2_f32 (the same 512 B feed 64 cycles), and the contraction of a strip is split over S
+// workgroups (96 strips x 8 = 768 = three resident per CU at D = 3072): each leaves its partial tile in the workspace
+// (30 us against 48 for the product, tools/ubench/rh_strip32), and a second, small launch per product adds the S tiles
+// of a strip in split order and runs the epilogue (BatchNorm statistics, activation, residual update).  The kernel
+// boundary is the hand-off: an in-kernel one (the workgroup whose ticket comes last finishes the strip) was built and
+// measured — with the agent-scope release / acquire the non-coherent per-XCD L2s need, it gave back all but 3 % of the
+// gain (254 us per forward + backward against 261; 117 us per PRODUCT with __threadfence() in every thread).
+constexpr int kS32Threads = 256, kS32Cols = 32, kS32Bk = 32, kS32Lda = kS32Bk + 4, kS32LdN = kS32Cols + 4;
+constexpr int kS32TileFloats = 4 * 64 * 16;              // one partial tile: [wave][4][lane] float4
+
+template <bool NT>
+__device__ __forceinline__ void strip32_gemm(const float* __restrict__ X, int B, int klen, int ldx, const float* __restrict__ W,
+                                             int ldw, int n0, f32x16& acc, float* As, float* Ws) {
+    constexpr int BK = kS32Bk, LDA = kS32Lda, C4 = BK / 4;
+    constexpr int ASZ = kRhRows32 * LDA, WSZ = NT ? kS32Cols * LDA : BK * kS32LdN;
+    constexpr int APT = kRhRows32 * C4 / kS32Threads;    // X-slab float4 per thread (4); the W slab is one float4 per thread
+    static_assert(kS32Cols * BK / 4 == kS32Threads, "one operand float4 per thread");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, jj = lane & 31, kh = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float4 pa[APT], pw;
+    auto fetch = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < APT; ++m) {
+            const int f = tid + kS32Threads * m, row = f / C4, c4 = f % C4;
+            const int rc = row < B ? row : B - 1;         // rows beyond the batch: re-read the last one, zeroed when staged
+            pa[m] = *reinterpret_cast<const float4*>(X + (size_t)rc * ldx + k0 + 4 * c4);
+        }
+        if (NT) {
+            const int row = tid / C4, c4 = tid % C4;      // feature n0 + row, k0 + 4 c4
+            pw = *reinterpret_cast<const float4*>(W + (size_t)(n0 + row) * ldw + k0 + 4 * c4);
+        } else {
+            const int row = tid / (kS32Cols / 4), c4 = tid % (kS32Cols / 4);   // k0 + row, features n0 + 4 c4
+            pw = *reinterpret_cast<const float4*>(W + (size_t)(k0 + row) * ldw + n0 + 4 * c4);
+        }
+    };
+    auto stage = [&](int buf) __attribute__((always_inline)) {
+        float* A = As + buf * ASZ;
+        float* Wb = Ws + buf * WSZ;
+#pragma unroll
+        for (int m = 0; m < APT; ++m) {
+            const int f = tid + kS32Threads * m, row = f / C4, c4 = f % C4;
+            *reinterpret_cast<float4*>(A + row * LDA + 4 * c4) = row < B ? pa[m] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (NT) {
+            const int row = tid / C4, c4 = tid % C4;
+            *reinterpret_cast<float4*>(Wb + row * LDA + 4 * c4) = pw;
+        } else {
+            const int row = tid / (kS32Cols / 4), c4 = tid % (kS32Cols / 4);
+            *reinterpret_cast<float4*>(Wb + row * kS32LdN + 4 * c4) = pw;
+        }
+    };
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < klen; k0 += BK) {
+        const bool more = k0 + BK < klen;
+        if (more) fetch(k0 + BK);
+        const float* A = As + buf * ASZ;
+        const float* Wb = Ws + buf * WSZ;
+#pragma unroll
+        for (int g = 0; g < BK / 8; ++g) {                // 8 k's = 4 MFMAs: half-wave kh takes k = 8 g + 4 kh + s in step s
+            const float4 av = *reinterpret_cast<const float4*>(A + (wave * 32 + jj) * LDA + 8 * g + 4 * kh);
+            float b[4];
+            if (NT) {
+                const float4 bv = *reinterpret_cast<const float4*>(Wb + jj * LDA + 8 * g + 4 * kh);
+                b[0] = bv.x; b[1] = bv.y; b[2] = bv.z; b[3] = bv.w;
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) b[s] = Wb[(8 * g + 4 * kh + s) * kS32LdN + jj];
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b[2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b[3], acc, 0, 0, 0);
+        }
+        if (more) stage(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+}
+
+// batch row of accumulator component r (column = n0 + (lane & 31)): the 32 x 32 accumulator layout
+__device__ __forceinline__ int acc32_row(int wave, int r, int kh) { return wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh; }
+
+// partial tile of (strip, split): [wave][4][lane] float4, lane-major, so that stores and loads are whole 1 KB rows
+__device__ __forceinline__ void strip32_store(const f32x16& acc, float* part, int strip, int split, int S) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4* mine = reinterpret_cast<f32x4*>(part + ((size_t)strip * S + split) * kS32TileFloats) + wave * 4 * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) mine[q * 64] = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+}
+// ---- epilogue launches: one workgroup per (strip, column quarter) = 128 rows x 8 columns, thread t = ((w * 4 + q) * 2
+// + kh) * 8 + j holds the float4 of tile wave w, register quad q, lane kh * 32 + 8 * quarter + j: rows
+// 32 w + 8 q + 4 kh + (0..3) of column 8 * quarter + j.  (One workgroup per strip — 96 of them — took 8-11 us per
+// launch: too few loads in flight.)
+struct Epi32 {
+    int w, q, kh, j, col, row0;                           // row0: first of my four consecutive batch rows
+    __device__ __forceinline__ Epi32(int strip, int quarter) {
+        const int t = threadIdx.x;
+        j = t & 7; kh = (t >> 3) & 1; q = (t >> 4) & 3; w = t >> 6;
+        col = strip * kS32Cols + 8 * quarter + j;
+        row0 = 32 * w + 8 * q + 4 * kh;
+    }
+};
+// the S partial tiles of a strip added in split order (the loads of four tiles in flight together)
+__device__ __forceinline__ f32x4 strip32_sum(const float* part, int strip, int quarter, int S, const Epi32& e) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const size_t at = (size_t)(e.w * 4 + e.q) * 64 + e.kh * 32 + 8 * quarter + e.j;
+    for (int s0 = 0; s0 < S; s0 += 4) {
+        f32x4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int sc = s0 + i < S ? s0 + i : S - 1;
+            v[i] = reinterpret_cast<const f32x4*>(part + ((size_t)strip * S + sc) * kS32TileFloats)[at];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (s0 + i < S) acc += v[i];
+    }
+    return acc;
+}
+// sum over the workgroup of a per-thread value that belongs to column (t & 7): every thread gets its column's total
+__device__ __forceinline__ float column_total8(float v, float* red) {
+    v += __shfl_xor(v, 8, 64);                            // fixed order: deterministic
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    const int t = threadIdx.x;
+    __syncthreads();
+    if ((t & 63) < 8) red[(t >> 6) * 8 + (t & 7)] = v;
+    __syncthreads();
+    return (red[t & 7] + red[8 + (t & 7)]) + (red[16 + (t & 7)] + red[24 + (t & 7)]);
+}
+
+struct RhPartArgs { const float* X; const float* W; float* part; int B, D, S; };
+
+// partial products of a strip: blockIdx.y = slice of the contraction
+template <bool NT>
+__global__ __launch_bounds__(kS32Threads) void rh_part32_kernel(RhPartArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float rh_smem[];
+    float* As = rh_smem;                                                 // [2][128][LDA]
+    float* Ws = As + 2 * kRhRows32 * kS32Lda;                            // [2][32][LDA] / [2][BK][LdN]
+    const int strip = blockIdx.x, split = blockIdx.y, n0 = strip * kS32Cols;
+    const int klen = a.D / a.S, kb = split * klen;
+    f32x16 acc;
+    strip32_gemm<NT>(a.X + kb, a.B, klen, a.D, NT ? a.W + kb : a.W + (size_t)kb * a.D, a.D, n0, acc, As, Ws);
+    strip32_store(acc, a.part, strip, split, a.S);
+}
+
+// P = sum of the partial tiles; BatchNorm1d over the batch (cifar_2version.py:201, 214-215), activation (:216)
+__global__ __launch_bounds__(kS32Threads) void rh_fwd32_epi_kernel(RhFwdArgs a, const float* part, int S) {
+    __shared__ float red[32];
+    const Epi32 e(blockIdx.x, blockIdx.y);
+    f32x4 acc = strip32_sum(part, blockIdx.x, blockIdx.y, S, e);
+    const int col = e.col;
+    float mu, istd;
+    if (a.training) {
+        mu = column_total8((acc[0] + acc[1]) + (acc[2] + acc[3]), red) / (float)a.B;      // padded rows hold exact zeros
+        float q = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float dlt = acc[r] - mu;
+            if (e.row0 + r < a.B) q = fmaf(dlt, dlt, q);
+        }
+        const float var = column_total8(q, red) / (float)a.B;              // biased, as BatchNorm normalises
+        istd = 1.0f / sqrtf(var + a.eps);
+        if (threadIdx.x < 8 && a.run_mean != nullptr) {                   // running statistics (unbiased variance)
+            const float unb = a.B > 1 ? var * (float)a.B / (float)(a.B - 1) : var;
+            a.run_mean[col] = (1.f - a.momentum) * a.run_mean[col] + a.momentum * mu;
+            a.run_var[col] = (1.f - a.momentum) * a.run_var[col] + a.momentum * unb;
+        }
+    } else {
+        mu = a.run_mean[col];
+        istd = 1.0f / sqrtf(a.run_var[col] + a.eps);
+    }
+    if (threadIdx.x < 8) { a.mean[col] = mu; a.invstd[col] = istd; }
+    const float g = a.gamma[col], bt = a.beta[col];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = e.row0 + r;
+        if (row < a.B) {
+            const float p = acc[r];
+            a.P[(size_t)row * a.D + col] = p;
+            a.H[(size_t)row * a.D + col] = act_fwd(fmaf((p - mu) * istd, g, bt), a.act);
+        }
+    }
+}
+
+// out = base + scale * (sum of the partial tiles)
+__global__ __launch_bounds__(kS32Threads) void rh_axpy32_epi_kernel(RhAxpyArgs a, const float* part, int S) {
+    const Epi32 e(blockIdx.x, blockIdx.y);
+    const f32x4 acc = strip32_sum(part, blockIdx.x, blockIdx.y, S, e);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = e.row0 + r;
+        if (row < a.B) {
+            const size_t o = (size_t)row * a.D + e.col;
+            a.out[o] = a.base != nullptr ? fmaf(a.scale, acc[r], a.base[o]) : a.scale * acc[r];
+        }
+    }
+}
+
+// dH = scale * (sum of the partial tiles of G K^T); through the activation and the BatchNorm -> dP, dgamma, dbeta
+__global__ __launch_bounds__(kS32Threads) void rh_bwd32_epi_kernel(RhBwdArgs a, const float* part, int S) {
+    __shared__ float red[32];
+    const Epi32 e(blockIdx.x, blockIdx.y);
+    f32x4 acc = strip32_sum(part, blockIdx.x, blockIdx.y, S, e);
+    const int col = e.col;
+    const float mu = a.mean[col], istd = a.invstd[col], g = a.gamma[col];
+    float sb = 0.f, sg = 0.f;
+    f32x4 xh;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = e.row0 + r;
+        float dhn = 0.f, xhat = 0.f;
+        if (row < a.B) {
+            const size_t o = (size_t)row * a.D + col;
+            dhn = a.scale * acc[r] * act_bwd(a.H[o], a.act);
+            xhat = (a.P[o] - mu) * istd;
+        }
+        acc[r] = dhn;
+        xh[r] = xhat;
+        sb += dhn;
+        sg = fmaf(dhn, xhat, sg);
+    }
+    const float dbeta = column_total8(sb, red);
+    const float dgamma = column_total8(sg, red);
+    if (threadIdx.x < 8) { a.g_beta[col] = dbeta; a.g_gamma[col] = dgamma; }
+    const float inv_b = 1.0f / (float)a.B;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = e.row0 + r;
+        if (row < a.B) {
+            const float dhn = acc[r];
+            a.dP[(size_t)row * a.D + col] = a.training ? g * istd * (dhn - (dbeta + xh[r] * dgamma) * inv_b) : g * istd * dhn;
+        }
+    }
+}
+
 struct RhOuterArgs {
     const float* A1; const float* B1; const float* A2; const float* B2;
     float* out;
@@ -650,6 +895,31 @@ int launch_strip(KERN kern, const ARGS& a, int D, int row_blocks, hipStream_t st
 
 bool rh_dims_ok(int B, int D) { return B >= 1 && D >= 64 && (D % 64) == 0; }
 
+// the split of a 32-column strip's contraction: a power of two (2..8), slices of whole 32-wide slabs and at least two of
+// them, at most ~4 workgroups per CU; 0 = this batch / width keeps the 16-column kernels
+int rh_split32(int B, int D) {
+    static const bool off = getenv("PDE_RH_NO_STRIP32") != nullptr;
+    if (off || B > kRhRows32) return 0;
+    int S = 8;
+    while (S > 1 && (D % (S * 2 * kS32Bk) != 0 || (D / kS32Cols) * S > 1024)) S >>= 1;
+    return S >= 2 ? S : 0;
+}
+size_t rh_split32_bytes(int D, int S) { return S < 2 ? 0 : (size_t)(D / kS32Cols) * S * kS32TileFloats * sizeof(float); }
+constexpr size_t strip32_lds() {
+    return (size_t)(2 * kRhRows32 * kS32Lda + 2 * (kS32Cols * kS32Lda > kS32Bk * kS32LdN ? kS32Cols * kS32Lda : kS32Bk * kS32LdN))
+           * sizeof(float);
+}
+// partial products X W^T (NT) or X W (NN) of every strip into `ws`
+template <bool NT>
+int launch_part32(const float* X, const float* W, int B, int D, int S, void* ws, hipStream_t st) {
+    static unsigned long long configured = 0;
+    if (ensure_dynamic_lds(reinterpret_cast<const void*>(rh_part32_kernel<NT>), (int)strip32_lds(), configured) != PDE_OK)
+        return PDE_E_LAUNCH;
+    RhPartArgs a{X, W, static_cast<float*>(ws), B, D, S};
+    hipLaunchKernelGGL(rh_part32_kernel<NT>, dim3(D / kS32Cols, S), dim3(kS32Threads), strip32_lds(), st, a);
+    return check_launch();
+}
+
 }  // namespace
 }  // namespace pde
 
@@ -659,10 +929,15 @@ extern "C" {
 
 int pde_sym_layer_supported(int32_t B, int32_t D) { return rh_dims_ok(B, D) ? 1 : 0; }
 
+size_t pde_sym_layer_workspace_bytes(int32_t B, int32_t D) {
+    if (!rh_dims_ok(B, D)) return 0;
+    return rh_split32_bytes(D, rh_split32(B, D));
+}
+
 int pde_sym_layer_forward(int32_t B, int32_t D, int32_t act, int32_t training, const float* X, const float* K,
                           const float* bn_weight, const float* bn_bias, float* running_mean, float* running_var,
                           float momentum, float eps, const float* base, float scale, float* P, float* H, float* mean,
-                          float* invstd, float* out, void* stream) {
+                          float* invstd, float* out, void* workspace, size_t workspace_bytes, void* stream) {
     if (!rh_dims_ok(B, D)) return PDE_E_BADARG;
     if (!X || !K || !bn_weight || !bn_bias || !P || !H || !mean || !invstd || !out) return PDE_E_BADARG;
     if (act < kActIdentity || act > kActTanh) return PDE_E_BADARG;
@@ -671,6 +946,19 @@ int pde_sym_layer_forward(int32_t B, int32_t D, int32_t act, int32_t training, c
     RhFwdArgs f{X, K, bn_weight, bn_bias, running_mean, running_var, P, H, mean, invstd, B, D, act, training ? 1 : 0, momentum, eps};
     const int nblk = (B + kRhRows - 1) / kRhRows;
     int rc;
+    const int S = workspace ? rh_split32(B, D) : 0;       // no workspace: the 16-column kernels (one workgroup per strip)
+    if (S >= 2) {
+        if (workspace_bytes < rh_split32_bytes(D, S) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return PDE_E_WORKSPACE;
+        const float* part = static_cast<const float*>(workspace);
+        rc = launch_part32<true>(X, K, B, D, S, workspace, st);
+        if (rc != PDE_OK) return rc;
+        hipLaunchKernelGGL(rh_fwd32_epi_kernel, dim3(D / kS32Cols, 4), dim3(kS32Threads), 0, st, f, part, S);
+        rc = launch_part32<false>(H, K, B, D, S, workspace, st);
+        if (rc != PDE_OK) return rc;
+        RhAxpyArgs x{H, K, base, out, B, D, scale};
+        hipLaunchKernelGGL(rh_axpy32_epi_kernel, dim3(D / kS32Cols, 4), dim3(kS32Threads), 0, st, x, part, S);
+        return check_launch();
+    }
     if (nblk == 1) {                                      // the whole batch in one strip workgroup: statistics as epilogue
         rc = launch_strip(rh_fwd_strip_kernel<1>, f, D, 1, st);
     } else {                                              // product by row blocks, then the statistics over all of them
@@ -688,7 +976,7 @@ int pde_sym_layer_forward(int32_t B, int32_t D, int32_t act, int32_t training, c
 int pde_sym_layer_backward(int32_t B, int32_t D, int32_t act, int32_t training, const float* g_out, float scale,
                            const float* X, const float* K, const float* bn_weight, const float* P, const float* H,
                            const float* mean, const float* invstd, float* dP, float* gX, float* gK,
-                           float* g_bn_weight, float* g_bn_bias, void* stream) {
+                           float* g_bn_weight, float* g_bn_bias, void* workspace, size_t workspace_bytes, void* stream) {
     if (!rh_dims_ok(B, D)) return PDE_E_BADARG;
     if (!g_out || !X || !K || !bn_weight || !P || !H || !mean || !invstd || !dP || !gX || !gK || !g_bn_weight || !g_bn_bias)
         return PDE_E_BADARG;
@@ -697,7 +985,19 @@ int pde_sym_layer_backward(int32_t B, int32_t D, int32_t act, int32_t training, 
     RhBwdArgs b{g_out, K, bn_weight, P, H, mean, invstd, dP, g_bn_weight, g_bn_bias, B, D, act, training ? 1 : 0, scale};
     const int nblk = (B + kRhRows - 1) / kRhRows;
     int rc;
-    if (nblk == 1) {
+    const int S = workspace ? rh_split32(B, D) : 0;
+    if (S >= 2) {
+        if (workspace_bytes < rh_split32_bytes(D, S) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return PDE_E_WORKSPACE;
+        const float* part = static_cast<const float*>(workspace);
+        rc = launch_part32<true>(g_out, K, B, D, S, workspace, st);
+        if (rc != PDE_OK) return rc;
+        hipLaunchKernelGGL(rh_bwd32_epi_kernel, dim3(D / kS32Cols, 4), dim3(kS32Threads), 0, st, b, part, S);
+        rc = launch_part32<false>(dP, K, B, D, S, workspace, st);
+        if (rc != PDE_OK) return rc;
+        RhAxpyArgs x32{dP, K, nullptr, gX, B, D, 1.0f};
+        hipLaunchKernelGGL(rh_axpy32_epi_kernel, dim3(D / kS32Cols, 4), dim3(kS32Threads), 0, st, x32, part, S);
+        rc = check_launch();
+    } else if (nblk == 1) {
         rc = launch_strip(rh_bwd_strip_kernel<1>, b, D, 1, st);
     } else {
         RhAxpyArgs p{g_out, K, nullptr, dP, B, D, 1.0f};
@@ -707,9 +1007,11 @@ int pde_sym_layer_backward(int32_t B, int32_t D, int32_t act, int32_t training, 
         rc = check_launch();
     }
     if (rc != PDE_OK) return rc;
-    RhAxpyArgs x{dP, K, nullptr, gX, B, D, 1.0f};
-    rc = launch_strip(rh_axpy_strip_kernel<1>, x, D, nblk, st);
-    if (rc != PDE_OK) return rc;
+    if (S < 2) {
+        RhAxpyArgs x{dP, K, nullptr, gX, B, D, 1.0f};
+        rc = launch_strip(rh_axpy_strip_kernel<1>, x, D, nblk, st);
+        if (rc != PDE_OK) return rc;
+    }
     RhOuterArgs o{dP, X, H, g_out, gK, B, D, scale};
     // three-piece bf16 products on the same 64 x 192 tiles (57 us against 66 at B = 128, D = 3072; 128 x 192 and 128 x 128
     // tiles: 66 and 63 us); PDE_RH_NO_SPLIT=1 selects the fp32-MFMA kernel

@@ -952,6 +952,25 @@ def bn_pool(x, bn):
 _ACT_CODE = {"identity": 0, "relu": 1, "tanh": 2}
 
 
+_sym_ws = {}
+
+
+def _sym_workspace(B, D, dev):
+    """Scratch for the partial tiles of the symmetric layer's split strip products: kept per (device, stream, width) —
+    calls on one stream are ordered, calls on different streams get different buffers (and a captured graph keeps pointing
+    at memory that stays allocated)."""
+    n = L.load().pde_sym_layer_workspace_bytes(B, D)
+    if n == 0:
+        return None
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, D, n)
+    ws = _sym_ws.get(key)
+    if ws is None:
+        if len(_sym_ws) > 64:
+            _sym_ws.clear()
+        ws = _sym_ws[key] = torch.empty(n, dtype=torch.uint8, device=dev)
+    return ws
+
+
 class _SymLayerFn(torch.autograd.Function):
     """out = base + scale * (act(BatchNorm1d(X K^T)) K) — cifar_2version.py:190-258 — on the fp32 matrix cores (pde_rh.hip)."""
 
@@ -972,9 +991,11 @@ class _SymLayerFn(torch.autograd.Function):
         mean = torch.empty(D, dtype=torch.float32, device=dev)
         invstd = torch.empty_like(mean)
         with torch.cuda.device(dev):
+            ws = _sym_workspace(B, D, dev)
             L.check(lib.pde_sym_layer_forward(B, D, act, 1 if training else 0, _ptr(Xf), _ptr(Kf), _ptr(gm), _ptr(bt),
                                               _ptr(running_mean), _ptr(running_var), float(momentum), float(eps), _ptr(bs),
-                                              float(scale), _ptr(P), _ptr(H), _ptr(mean), _ptr(invstd), _ptr(out), _stream()),
+                                              float(scale), _ptr(P), _ptr(H), _ptr(mean), _ptr(invstd), _ptr(out),
+                                              _ptr(ws), 0 if ws is None else ws.numel(), _stream()),
                     "pde_sym_layer_forward")
         ctx.save_for_backward(Xf, Kf, gm, P, H, mean, invstd)
         ctx.cfg = (bool(training), float(scale), int(act), base is not None)
@@ -994,9 +1015,11 @@ class _SymLayerFn(torch.autograd.Function):
         gg = torch.empty(D, dtype=torch.float32, device=dev)
         gb = torch.empty_like(gg)
         with torch.cuda.device(dev):
+            ws = _sym_workspace(B, D, dev)
             L.check(lib.pde_sym_layer_backward(B, D, act, 1 if training else 0, _ptr(g), float(scale), _ptr(Xf), _ptr(Kf),
                                                _ptr(gm), _ptr(P), _ptr(H), _ptr(mean), _ptr(invstd), _ptr(dP), _ptr(gX),
-                                               _ptr(gK), _ptr(gg), _ptr(gb), _stream()), "pde_sym_layer_backward")
+                                               _ptr(gK), _ptr(gg), _ptr(gb), _ptr(ws), 0 if ws is None else ws.numel(),
+                                               _stream()), "pde_sym_layer_backward")
         return gX, gK, gg, gb, (g if has_base else None), None, None, None, None, None, None, None
 
 

@@ -378,20 +378,27 @@ int pde_jacobi_backward(int32_t B, int32_t H, int32_t W, int32_t nt,
  * and the unbiased variance, as torch.nn.BatchNorm1d does; running_* may be NULL = not tracked); training == 0:
  * running statistics.  P, H, mean[D], invstd[D] are written for the backward; base may be NULL (then out = scale*(H K)).
  * F_sym(Y) itself is base = NULL, scale = -1.  D a multiple of 64 (pde_sym_layer_supported); up to 128 batch rows the
- * statistics are the epilogue of the first product, larger batches run it by row blocks with a statistics pass beside it. */
+ * statistics are the epilogue of the first product, larger batches run it by row blocks with a statistics pass beside it.
+ * workspace: NULL, or pde_sym_layer_workspace_bytes(B, D) bytes of scratch (16-byte aligned; contents do not matter, no
+ * two calls that share it in flight at once): with it, batches up to 128 rows run each product as 32-column strips whose
+ * contraction is split over workgroups, the partial tiles added in a fixed order by a small second launch that also
+ * carries the epilogue.  Without it (or where pde_sym_layer_workspace_bytes is 0): one workgroup per 16-column strip. */
 int pde_sym_layer_supported(int32_t B, int32_t D);
+size_t pde_sym_layer_workspace_bytes(int32_t B, int32_t D);
 int pde_sym_layer_forward(int32_t B, int32_t D, int32_t act, int32_t training,
                           const float* X, const float* K, const float* bn_weight, const float* bn_bias,
                           float* running_mean, float* running_var, float momentum, float eps,
                           const float* base, float scale,
-                          float* P, float* H, float* mean, float* invstd, float* out, void* stream);
+                          float* P, float* H, float* mean, float* invstd, float* out,
+                          void* workspace, size_t workspace_bytes, void* stream);
 /* Backward of the above for an upstream gradient g_out (B, D) of `out` (the gradient of `base` is g_out itself and is
  * left to the caller).  dP: (B, D) scratch.  Overwritten: gX (B, D), gK (D, D) — both uses of K —, g_bn_weight[D],
- * g_bn_bias[D]. */
+ * g_bn_bias[D].  workspace: as in pde_sym_layer_forward (the same one may serve both). */
 int pde_sym_layer_backward(int32_t B, int32_t D, int32_t act, int32_t training,
                            const float* g_out, float scale, const float* X, const float* K, const float* bn_weight,
                            const float* P, const float* H, const float* mean, const float* invstd,
-                           float* dP, float* gX, float* gK, float* g_bn_weight, float* g_bn_bias, void* stream);
+                           float* dP, float* gX, float* gK, float* g_bn_weight, float* g_bn_bias,
+                           void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- utilities ------------------------------------------------------------------------- */
 

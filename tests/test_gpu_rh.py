@@ -145,14 +145,20 @@ def test_boundary_rejects_what_it_cannot_do():
     p = lambda t: C.c_void_p(t.data_ptr())
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     ok = lambda B, D, act, X: lib.pde_sym_layer_forward(B, D, act, 1, X, p(k), p(v), p(v), None, None, 0.1, 1e-5, None, -1.0,
-                                                        p(x), p(x), p(v), p(v), p(x), st)
+                                                        p(x), p(x), p(v), p(v), p(x), None, 0, st)
     assert ok(8, 64, 1, p(x)) == 0
     assert ok(8, 64, 1, None) == -1            # null pointer
     assert ok(8, 64, 7, p(x)) == -1            # unknown activation
     assert ok(8, 100, 1, p(x)) == -1           # feature count not a multiple of 64
     # eval mode needs running statistics
     assert lib.pde_sym_layer_forward(8, 64, 1, 0, p(x), p(k), p(v), p(v), None, None, 0.1, 1e-5, None, -1.0,
-                                     p(x), p(x), p(v), p(v), p(x), st) == -1
+                                     p(x), p(x), p(v), p(v), p(x), None, 0, st) == -1
+    # a workspace that is too small for the split kernels is refused, not silently ignored
+    assert lib.pde_sym_layer_workspace_bytes(8, 3072) > 0 and lib.pde_sym_layer_workspace_bytes(300, 3072) == 0
+    x3 = torch.zeros(8, 3072, device="cuda"); k3 = torch.zeros(3072, 3072, device="cuda"); v3 = torch.zeros(3072, device="cuda")
+    small = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    assert lib.pde_sym_layer_forward(8, 3072, 1, 1, p(x3), p(k3), p(v3), p(v3), None, None, 0.1, 1e-5, None, -1.0,
+                                     p(x3), p(x3), p(v3), p(v3), p(x3), p(small), small.numel(), st) == -5
     torch.cuda.synchronize()
 
 
@@ -167,3 +173,39 @@ def test_training_batch_of_one_row_raises_like_the_reference():
         m(torch.randn(1, 1, 8, 8, device="cuda"))
     m.eval()
     assert m(torch.randn(1, 1, 8, 8, device="cuda")).shape == (1, 1, 8, 8)
+
+
+@pytest.mark.gpu
+def test_split_contraction_under_uneven_load():
+    """The 32-column strip kernels leave partial tiles in a scratch buffer that is reused from call to call and added up
+    by a second launch (pde_rh.hip): 40 calls with fresh inputs (two batch sizes) while another stream keeps the memory
+    system busy, every element of every output compared with plain fp32 torch products (cifar_2version.py:210-219 without
+    the module)."""
+    from cnn_with_pde_amd import functional as F_
+    g = torch.Generator().manual_seed(5)
+    B, D = 128, 3072
+    bn = torch.nn.BatchNorm1d(D).cuda().train()
+    side = torch.cuda.Stream()
+    junk = torch.empty(64 << 20, device="cuda")
+    worst = 0.0
+    for it in range(40):
+        Kw = (torch.eye(D) + 0.02 * torch.randn(D, D, generator=g)).cuda().requires_grad_(True)
+        X = torch.randn(B if it % 3 else 61, D, generator=g).cuda().requires_grad_(True)
+        gy = torch.randn(X.shape[0], D, generator=g).cuda()
+        with torch.cuda.stream(side):
+            for _ in range(4):
+                junk.add_(1.0)
+        y = F_.sym_layer(X, Kw, bn, "tanh", base=None, scale=-1.0)
+        y.backward(gy)
+        Xr = X.detach().clone().requires_grad_(True)
+        Kr = Kw.detach().clone().requires_grad_(True)
+        P = Xr @ Kr.t()
+        Hn = (P - P.mean(0)) / torch.sqrt(P.var(0, unbiased=False) + bn.eps) * bn.weight.detach() + bn.bias.detach()
+        yr = -(torch.tanh(Hn) @ Kr)
+        yr.backward(gy)
+        torch.cuda.synchronize()
+        for a, b in ((y, yr), (X.grad, Xr.grad), (Kw.grad, Kr.grad)):
+            worst = max(worst, float((a.detach() - b.detach()).abs().max() / b.detach().abs().max()))
+        bn.weight.grad = None
+        bn.bias.grad = None
+    assert worst < 2e-5, worst
