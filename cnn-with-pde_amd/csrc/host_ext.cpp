@@ -14,6 +14,8 @@
 #include <hip/hip_runtime_api.h>
 
 #include <atomic>
+#include <map>
+#include <tuple>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -623,6 +625,90 @@ variable_list multi(const Tensor& u, const std::optional<Tensor>& weights, std::
     return MultiFn::apply(u, wo, at::TensorList(flat), desc_addrs, sps, want_sums, ckpt_mode, masks, amax, need_grad);
 }
 
+
+// ---- the Ruthotto-Haber symmetric layer (functional._SymLayerFn: cifar_2version.py:190-258) ----------------------------
+// out = base + scale * (act(BatchNorm1d(X K^T)) K).  Scratch for the split strip products is kept per (device, stream,
+// width): calls on one stream are ordered, and a captured graph keeps pointing at memory that stays allocated.
+Tensor sym_workspace(int64_t B, int64_t D, const Tensor& like, hipStream_t st) {
+    const size_t n = pde_sym_layer_workspace_bytes((int32_t)B, (int32_t)D);
+    if (n == 0) return Tensor();
+    static std::mutex mu;
+    static std::map<std::tuple<int, void*, int64_t, size_t>, Tensor> cache;
+    std::lock_guard<std::mutex> g(mu);
+    auto key = std::make_tuple((int)like.device().index(), (void*)st, D, n);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    if (cache.size() > 64) cache.clear();
+    Tensor ws = at::empty({(int64_t)n}, like.options().dtype(at::kByte));
+    cache.emplace(key, ws);
+    return ws;
+}
+
+struct SymFn : public torch::autograd::Function<SymFn> {
+    static Tensor forward(AutogradContext* ctx, const Tensor& X, const Tensor& K, const Tensor& gamma, const Tensor& beta,
+                          const std::optional<Tensor>& base, const std::optional<Tensor>& run_mean,
+                          const std::optional<Tensor>& run_var, bool training, double momentum, double eps, double scale,
+                          int64_t act, bool need_grad) {
+        PDE_REQUIRE(X.is_cuda() && K.is_cuda() && gamma.is_cuda() && beta.is_cuda() && (!base.has_value() || base->is_cuda()),
+                    "libpdecnn_hip operators need CUDA/HIP tensors (there is no CPU fallback)");
+        PDE_REQUIRE(X.dim() == 2 && K.dim() == 2 && K.size(0) == X.size(1) && K.size(1) == X.size(1), "expected X (B, D), K (D, D)");
+        const int64_t B = X.size(0), D = X.size(1);
+        Tensor Xf = as_f32(X), Kf = as_f32(K), gm = as_f32(gamma), bt = as_f32(beta);
+        Tensor bs = base.has_value() ? as_f32(*base) : Tensor();
+        c10::hip::HIPGuardMasqueradingAsCUDA guard(X.device());
+        hipStream_t st = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(X.device().index()).stream();
+        Tensor P = at::empty({B, D}, Xf.options()), H = at::empty({B, D}, Xf.options()), out = at::empty({B, D}, Xf.options());
+        Tensor mean = at::empty({D}, Xf.options()), invstd = at::empty({D}, Xf.options());
+        Tensor ws = sym_workspace(B, D, Xf, st);
+        float* rm = run_mean.has_value() ? run_mean->data_ptr<float>() : nullptr;
+        float* rv = run_var.has_value() ? run_var->data_ptr<float>() : nullptr;
+        check(pde_sym_layer_forward((int32_t)B, (int32_t)D, (int32_t)act, training ? 1 : 0, Xf.data_ptr<float>(),
+                                    Kf.data_ptr<float>(), gm.data_ptr<float>(), bt.data_ptr<float>(), rm, rv, (float)momentum,
+                                    (float)eps, bs.defined() ? bs.data_ptr<float>() : nullptr, (float)scale, P.data_ptr<float>(),
+                                    H.data_ptr<float>(), mean.data_ptr<float>(), invstd.data_ptr<float>(), out.data_ptr<float>(),
+                                    ws.defined() ? ws.data_ptr() : nullptr, ws.defined() ? (size_t)ws.numel() : 0, (void*)st),
+              "pde_sym_layer_forward");
+        if (need_grad) {
+            ctx->save_for_backward({Xf, Kf, gm, P, H, mean, invstd});
+            ctx->saved_data["cfg"] = std::vector<int64_t>{training ? 1 : 0, act, base.has_value() ? 1 : 0};
+            ctx->saved_data["scale"] = scale;
+        }
+        return out;
+    }
+
+    static variable_list backward(AutogradContext* ctx, variable_list grads) {
+        auto sv = ctx->get_saved_variables();
+        const Tensor &Xf = sv[0], &Kf = sv[1], &gm = sv[2], &P = sv[3], &H = sv[4], &mean = sv[5], &invstd = sv[6];
+        auto cfg = ctx->saved_data["cfg"].toIntVector();
+        const double scale = ctx->saved_data["scale"].toDouble();
+        const int64_t B = Xf.size(0), D = Xf.size(1);
+        c10::hip::HIPGuardMasqueradingAsCUDA guard(Xf.device());
+        hipStream_t st = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(Xf.device().index()).stream();
+        Tensor g = grads[0];
+        if (g.scalar_type() != at::kFloat) g = g.to(at::kFloat);
+        g = g.contiguous();
+        Tensor dP = at::empty_like(Xf), gX = at::empty_like(Xf), gK = at::empty_like(Kf);
+        Tensor gg = at::empty({D}, Xf.options()), gb = at::empty({D}, Xf.options());
+        Tensor ws = sym_workspace(B, D, Xf, st);
+        check(pde_sym_layer_backward((int32_t)B, (int32_t)D, (int32_t)cfg[1], (int32_t)cfg[0], g.data_ptr<float>(), (float)scale,
+                                     Xf.data_ptr<float>(), Kf.data_ptr<float>(), gm.data_ptr<float>(), P.data_ptr<float>(),
+                                     H.data_ptr<float>(), mean.data_ptr<float>(), invstd.data_ptr<float>(), dP.data_ptr<float>(),
+                                     gX.data_ptr<float>(), gK.data_ptr<float>(), gg.data_ptr<float>(), gb.data_ptr<float>(),
+                                     ws.defined() ? ws.data_ptr() : nullptr, ws.defined() ? (size_t)ws.numel() : 0, (void*)st),
+              "pde_sym_layer_backward");
+        return {gX, gK, gg, gb, cfg[2] ? g : Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+    }
+};
+
+Tensor sym(const Tensor& X, const Tensor& K, const Tensor& gamma, const Tensor& beta, const std::optional<Tensor>& base,
+           const std::optional<Tensor>& run_mean, const std::optional<Tensor>& run_var, bool training, double momentum, double eps,
+           double scale, int64_t act) {
+    const bool need_grad = at::GradMode::is_enabled() && (X.requires_grad() || K.requires_grad() || gamma.requires_grad() ||
+                                                          beta.requires_grad() || (base.has_value() && base->requires_grad()));
+    auto opt = [](const std::optional<Tensor>& t) { return (t.has_value() && t->defined()) ? t : std::optional<Tensor>(); };
+    return SymFn::apply(X, K, gamma, beta, opt(base), opt(run_mean), opt(run_var), training, momentum, eps, scale, act, need_grad);
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -637,6 +723,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("multi", &multi, "functional.adi_diffuse_multi: layers that share an input, one launch per pass",
           py::arg("u"), py::arg("weights"), py::arg("flat"), py::arg("desc_addrs"), py::arg("sweeps_per_step"),
           py::arg("want_sums"), py::arg("ckpt_mode"), py::arg("masks"), py::arg("amax"));
+    m.def("sym", &sym, "functional.sym_layer's autograd node: out = base + scale * (act(BatchNorm1d(X K^T)) K)",
+          py::arg("X"), py::arg("K"), py::arg("gamma"), py::arg("beta"), py::arg("base"), py::arg("running_mean"),
+          py::arg("running_var"), py::arg("training"), py::arg("momentum"), py::arg("eps"), py::arg("scale"), py::arg("act"));
     m.def("set_error_class", [](py::object cls) {
         Py_XDECREF(g_error_class);
         g_error_class = cls.release().ptr();

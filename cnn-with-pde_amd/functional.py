@@ -1060,8 +1060,14 @@ def sym_layer(X, K, bn, activation: str = "relu", base=None, scale: float = -1.0
     if bn.training and track and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     b2 = None if base is None else base.reshape(B, -1)
-    out = _SymLayerFn.apply(X2, K, bn.weight, bn.bias, b2, rm, rv, training, bn.momentum if bn.momentum is not None else 0.0,
-                            bn.eps, scale, _ACT_CODE[activation])
+    mom = bn.momentum if bn.momentum is not None else 0.0
+    H_ = L.host_ext()
+    if H_ is not None and X2.is_cuda:
+        # the native host path (csrc/host_ext.cpp): the same two calls of the C ABI from a C++ autograd node
+        out = H_.sym(X2, K, bn.weight, bn.bias, b2, rm, rv, bool(training), float(mom), float(bn.eps), float(scale),
+                     _ACT_CODE[activation])
+    else:
+        out = _SymLayerFn.apply(X2, K, bn.weight, bn.bias, b2, rm, rv, training, mom, bn.eps, scale, _ACT_CODE[activation])
     return out.view(shape)
 
 

@@ -187,3 +187,33 @@ def test_shared_input_layers_match_bitwise(ck, sums, use_w):
             vals += [t.detach().clone() for t in res[2]]
         return vals + _grads_of(trio, [xx] + ([w] if w is not None else []))
     _both_paths(fn)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,training,with_base", [(64, True, False), (128, True, True), (33, False, True), (300, True, False)])
+def test_symmetric_layer_node_matches_bitwise(B, training, with_base):
+    """cifar_2version.py:190-258: the C++ node of functional.sym_layer against functional._SymLayerFn (running statistics
+    included: both start from the same buffers)."""
+    from cnn_with_pde_amd import functional as F_
+    g = torch.Generator().manual_seed(B)
+    D = 192
+    K = (torch.eye(D) + 0.05 * torch.randn(D, D, generator=g)).cuda()
+    X = torch.randn(B, D, generator=g).cuda()
+    base = torch.randn(B, D, generator=g).cuda() if with_base else None
+    gy = torch.randn(B, D, generator=g).cuda()
+    rm0, rv0 = 0.1 * torch.randn(D, generator=g).cuda(), (0.5 + torch.rand(D, generator=g)).cuda()
+
+    def fn(native):
+        bn = torch.nn.BatchNorm1d(D).cuda().train(training)
+        with torch.no_grad():
+            bn.running_mean.copy_(rm0); bn.running_var.copy_(rv0)
+        Kp, Xp = K.clone().requires_grad_(True), X.clone().requires_grad_(True)
+        bp = None if base is None else base.clone().requires_grad_(True)
+        y = F_.sym_layer(Xp, Kp, bn, "tanh", base=bp, scale=0.7)
+        node = y.grad_fn.next_functions[0][0]             # behind the view back to X's shape
+        assert (type(node).__name__ == "CppFunction") == native and (type(node).__name__ == "_SymLayerFnBackward") != native
+        y.backward(gy)
+        torch.cuda.synchronize()
+        return [y.detach().clone(), Xp.grad, Kp.grad, bn.weight.grad, bn.bias.grad, bn.running_mean.clone(), bn.running_var.clone(),
+                None if bp is None else bp.grad]
+    _both_paths(fn)
