@@ -414,6 +414,108 @@ Tensor small(const Tensor& u, const Tensor& ab, const Tensor& bb, const Tensor& 
     return SmallFn::apply(u, ab, bb, asl, bsl, M, sko, desc_addr, sps, mode, ckpt_mode, ckpt_lo, amax, need_grad);
 }
 
+// ---- one layer with a channel operator between its steps at any width: one factorisation, then per step one mixing and
+// one sweep launch (or the whole forward in one launch at C = 32 / 64), looped inside the library
+// (functional._AdiMixedFn: cifar10.py:84-112 "pre", SVHN.py:55-72 "post") -------------------------------------------------
+struct MixedFn : public torch::autograd::Function<MixedFn> {
+    static Tensor forward(AutogradContext* ctx, const Tensor& u_in, const Tensor& ab, const Tensor& bb, const Tensor& asl,
+                          const Tensor& bsl, const Tensor& M, int64_t desc_addr, int64_t sps, int64_t mode, int64_t ckpt_mode,
+                          int64_t ckpt_lo, double amax, bool need_grad) {
+        PDE_REQUIRE(u_in.is_cuda() && ab.is_cuda() && bb.is_cuda() && asl.is_cuda() && bsl.is_cuda() && M.is_cuda(),
+                    "libpdecnn_hip operators need CUDA/HIP tensors (there is no CPU fallback)");
+        PDE_REQUIRE(u_in.dim() == 4 && u_in.size(2) == u_in.size(3), "expected (B,C,N,N), got ", u_in.sizes());
+        PdeAdiDesc d;
+        std::memcpy(&d, reinterpret_cast<const void*>(desc_addr), sizeof(d));
+        const int64_t B = u_in.size(0), C = u_in.size(1), N = u_in.size(2);
+        Tensor u = u_in.detach();
+        if (u.scalar_type() != at::kFloat && u.scalar_type() != at::kBFloat16) u = u.to(at::kFloat);
+        u = u.contiguous();
+        PDE_REQUIRE(d.B == B && d.C == C && d.N == N && d.io_dtype == (u.scalar_type() == at::kBFloat16 ? PDE_IO_BF16 : PDE_IO_F32),
+                    "descriptor does not match the tensor");
+        const int64_t K = d.num_sweeps / sps;
+        Tensor p[4] = {as_chw(ab, C, N), as_chw(bb, C, N), as_chw(asl, C, N), as_chw(bsl, C, N)};
+        Tensor Mf = as_f32(M);
+        const bool want_kmax = need_grad && ckpt_mode == 1;
+        c10::hip::HIPGuardMasqueradingAsCUDA guard(u.device());
+        hipStream_t st = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(u.device().index()).stream();
+        Tensor sws = bytes(pde_adi_steps_workspace_bytes(&d, (int32_t)sps), u);
+        Tensor kdev, ticket;
+        Slot* slot = nullptr;
+        if (want_kmax) {
+            kdev = at::empty({(int64_t)d.num_sweeps}, u.options().dtype(at::kFloat));
+            slot = acquire_slot(u.device().index());
+            ticket = slot_ticket(slot, d.num_sweeps);
+        }
+        // states[k][0]: output of the step's first operator, states[k][1]: of its second (= input of step k + 1)
+        std::vector<int64_t> sh{K, 2};
+        for (auto v : u.sizes()) sh.push_back(v);
+        Tensor states = at::empty(sh, u.options());
+        check(pde_adi_mixed_forward(&d, (int32_t)sps, (int32_t)mode, u.data_ptr(), states.data_ptr(), Mf.data_ptr<float>(),
+                                    p[0].data_ptr<float>(), p[1].data_ptr<float>(), p[2].data_ptr<float>(), p[3].data_ptr<float>(),
+                                    want_kmax ? kdev.data_ptr<float>() : nullptr, slot ? slot->host : nullptr,
+                                    slot ? (void*)slot->ev : nullptr, sws.data_ptr(), (size_t)sws.numel(), (void*)st),
+              "pde_adi_mixed_forward");
+        if (need_grad) {
+            ctx->save_for_backward({u, states, Mf, p[0], p[1], p[2], p[3]});
+            ctx->saved_data["sws"] = sws;
+            if (slot) {
+                ctx->saved_data["ticket"] = ticket;
+                ctx->saved_data["slot"] = (int64_t) reinterpret_cast<intptr_t>(slot);
+            }
+            ctx->saved_data["desc"] = std::string(reinterpret_cast<const char*>(&d), sizeof(d));
+            ctx->saved_data["cfg"] = std::vector<int64_t>{sps, mode, ckpt_mode, ckpt_lo, (int64_t)M.scalar_type()};
+            ctx->saved_data["amax"] = amax;
+            ctx->saved_data["sh0"] = ab.sizes().vec();
+            ctx->saved_data["sh1"] = bb.sizes().vec();
+            ctx->saved_data["sh2"] = asl.sizes().vec();
+            ctx->saved_data["sh3"] = bsl.sizes().vec();
+        }
+        return states.select(0, K - 1).select(0, 1).clone();   // never a view of the kept states: callers may write to their result
+    }
+
+    static variable_list backward(AutogradContext* ctx, variable_list grads) {
+        auto saved = ctx->get_saved_variables();
+        const Tensor &u = saved[0], &states = saved[1], &Mf = saved[2];
+        PdeAdiDesc d;
+        std::memcpy(&d, ctx->saved_data["desc"].toStringRef().data(), sizeof(d));
+        auto cfg = ctx->saved_data["cfg"].toIntVector();
+        const int sps = (int)cfg[0], mode = (int)cfg[1], K = d.num_sweeps / sps;
+        uint64_t mask[2] = {(uint64_t)cfg[3], 0};
+        if (cfg[2] == 1) {
+            Slot* slot = reinterpret_cast<Slot*>((intptr_t)ctx->saved_data["slot"].toInt());
+            wait_event(slot->ev);
+            plan_steps(slot->host, K, sps, ctx->saved_data["amax"].toDouble(), mask);
+        }
+        c10::hip::HIPGuardMasqueradingAsCUDA guard(u.device());
+        hipStream_t st = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(u.device().index()).stream();
+        Tensor gy = grads[0];
+        if (gy.scalar_type() != u.scalar_type()) gy = gy.to(u.scalar_type());
+        gy = gy.contiguous();
+        Tensor gu = at::empty_like(gy);
+        static const char* const kShape[4] = {"sh0", "sh1", "sh2", "sh3"};
+        Tensor gp[4];
+        for (int i = 0; i < 4; ++i) gp[i] = at::empty(ctx->saved_data[kShape[i]].toIntVector(), saved[3 + i].options());
+        Tensor gM = at::empty_like(Mf);
+        Tensor ws = bytes(pde_adi_mixed_backward_workspace_bytes(&d, sps, popcount2(mask)), u);
+        Tensor sws = ctx->saved_data["sws"].toTensor();
+        check(pde_adi_mixed_backward(&d, sps, mode, gy.data_ptr(), u.data_ptr(), states.data_ptr(), Mf.data_ptr<float>(), mask,
+                                     gu.data_ptr(), saved[3].data_ptr<float>(), saved[4].data_ptr<float>(),
+                                     saved[5].data_ptr<float>(), saved[6].data_ptr<float>(), gp[0].data_ptr<float>(),
+                                     gp[1].data_ptr<float>(), gp[2].data_ptr<float>(), gp[3].data_ptr<float>(),
+                                     gM.data_ptr<float>(), sws.data_ptr(), ws.data_ptr(), (size_t)ws.numel(), (void*)st),
+              "pde_adi_mixed_backward");
+        if ((int64_t)gM.scalar_type() != cfg[4]) gM = gM.to((at::ScalarType)cfg[4]);
+        return {gu, gp[0], gp[1], gp[2], gp[3], gM, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+    }
+};
+
+Tensor mixed(const Tensor& u, const Tensor& ab, const Tensor& bb, const Tensor& asl, const Tensor& bsl, const Tensor& M,
+             int64_t desc_addr, int64_t sps, int64_t mode, int64_t ckpt_mode, int64_t ckpt_lo, double amax) {
+    const bool need_grad = at::GradMode::is_enabled() && (u.requires_grad() || ab.requires_grad() || bb.requires_grad() ||
+                                                          asl.requires_grad() || bsl.requires_grad() || M.requires_grad());
+    return MixedFn::apply(u, ab, bb, asl, bsl, M, desc_addr, sps, mode, ckpt_mode, ckpt_lo, amax, need_grad);
+}
+
 // ---- several mixing-first layers on the SAME input, one launch per pass (functional._AdiMultiFn: cifar10.py:272-280,
 // cifar_2version.py:287-288).  Returns (sum_i w_i y_i, y_1 .. y_L[, s_1 .. s_L]) ----------------------------------------
 struct MultiFn : public torch::autograd::Function<MultiFn> {
@@ -720,6 +822,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
           py::arg("u"), py::arg("alpha_base"), py::arg("beta_base"), py::arg("alpha_time_coeff"), py::arg("beta_time_coeff"),
           py::arg("M"), py::arg("skip_weight"), py::arg("desc_addr"), py::arg("sweeps_per_step"), py::arg("mode"),
           py::arg("ckpt_mode"), py::arg("ckpt_lo"), py::arg("amax"));
+    m.def("mixed", &mixed, "functional.adi_diffuse_mixed: one layer with a channel operator between its steps, any width",
+          py::arg("u"), py::arg("alpha_base"), py::arg("beta_base"), py::arg("alpha_time_coeff"), py::arg("beta_time_coeff"),
+          py::arg("M"), py::arg("desc_addr"), py::arg("sweeps_per_step"), py::arg("mode"), py::arg("ckpt_mode"),
+          py::arg("ckpt_lo"), py::arg("amax"));
     m.def("multi", &multi, "functional.adi_diffuse_multi: layers that share an input, one launch per pass",
           py::arg("u"), py::arg("weights"), py::arg("flat"), py::arg("desc_addrs"), py::arg("sweeps_per_step"),
           py::arg("want_sums"), py::arg("ckpt_mode"), py::arg("masks"), py::arg("amax"));

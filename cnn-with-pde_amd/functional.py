@@ -793,6 +793,16 @@ def adi_diffuse_mixed(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coef
         if tickets and len(tickets) == len(steps):           # the whole layer's maxima, step after step (lagged plans)
             kmax_sink.append(_KmaxConcat(tickets))
         return u
+    if kmax_sink is None and (checkpoints == "auto" or isinstance(checkpoints, int)):
+        H = L.host_ext()
+        if H is not None and u.dim() == 4 and u.is_cuda and u.shape[2] == u.shape[3]:
+            # the native host path (csrc/host_ext.cpp): the same two calls of the C ABI from a C++ autograd node
+            B, Cc, N, _ = u.shape
+            flat = tuple(s for st in steps for s in st)
+            d = _make_desc(B, Cc, N, L.PDE_IO_BF16 if u.dtype == torch.bfloat16 else L.PDE_IO_F32, flat, smooth3, clamp_max, eps)
+            return H.mixed(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff, M, C.addressof(d), len(steps[0]),
+                           1 if mode == "pre" else 2, 1 if checkpoints == "auto" else 0,
+                           0 if checkpoints == "auto" else int(checkpoints), CKPT_AMAX)
     return _AdiMixedFn.apply(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff, M, steps, mode, bool(smooth3),
                              clamp_max, float(eps), checkpoints, kmax_sink)
 

@@ -217,3 +217,33 @@ def test_symmetric_layer_node_matches_bitwise(B, training, with_base):
         return [y.detach().clone(), Xp.grad, Kp.grad, bn.weight.grad, bn.bias.grad, bn.running_mean.clone(), bn.running_var.clone(),
                 None if bp is None else bp.grad]
     _both_paths(fn)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which,C_", [("cifar10", 8), ("svhn", 8), ("cifar10", 32)])
+@pytest.mark.parametrize("ck", ["auto", 0b10])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_per_step_layers_match_bitwise(which, C_, ck, dtype):
+    """Layers with a channel operator at widths above 4 (cifar10.py:84-112, SVHN.py:55-76): per-step launches or, at
+    C = 32 fp32, the one-launch forward — the C++ node against functional._AdiMixedFn."""
+    import cnn_with_pde_amd as P
+    g = torch.Generator().manual_seed(13 + C_)
+    with contextlib.redirect_stdout(io.StringIO()):
+        l = (P.EnhancedDiffusionLayer(32, C_, dt=0.05, num_steps=3) if which == "cifar10"
+             else P.SvhnDiffusionLayer(32, C_, dt=0.05, num_steps=3)).cuda()
+    with torch.no_grad():
+        l.beta_time_coeff.copy_(torch.randn(l.beta_time_coeff.shape, generator=g))
+        l.alpha_base.mul_(2.0)
+    l.checkpoint_policy = ck
+    x = torch.randn(6, C_, 32, 32, generator=g).to("cuda", dtype)
+    gy = torch.randn(6, C_, 32, 32, generator=g).to("cuda", dtype)
+
+    def fn(native):
+        for p in l.parameters():
+            p.grad = None
+        xx = x.clone().requires_grad_(True)
+        y = l(xx)
+        y.backward(gy)
+        torch.cuda.synchronize()
+        return [y.detach().clone()] + _grads_of([l], [xx])
+    _both_paths(fn)
