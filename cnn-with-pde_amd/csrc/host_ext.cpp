@@ -14,6 +14,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <atomic>
+#include <chrono>
 #include <map>
 #include <tuple>
 #include <cstring>
@@ -141,9 +142,17 @@ Tensor slot_ticket(Slot* s, int n) {
 }
 
 void wait_event(hipEvent_t ev) {
-    // expected within microseconds (the factorisation kernel right behind the forward's launch): poll before blocking
-    for (int i = 0; i < 20000; ++i)
-        if (hipEventQuery(ev) == hipSuccess) return;
+    // Expected within microseconds of the device reaching the factorisation kernel — but the device may still be busy with
+    // the previous step's backward when the host gets here (a device-bound loop: the host runs one pass ahead), so the poll
+    // is bounded by TIME, not by a number of queries: a query of a pending event costs 15 ns on some hosts and 1 us on
+    // others, and a blocking hipEventSynchronize costs 100-150 us to wake up from (0.60 ms per headline step instead of
+    // 0.49 where 20,000 queries ran out first).
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        for (int i = 0; i < 256; ++i)
+            if (hipEventQuery(ev) == hipSuccess) return;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+    }
     TORCH_CHECK(hipEventSynchronize(ev) == hipSuccess, "hipEventSynchronize failed");
 }
 

@@ -284,11 +284,16 @@ template <int C>
 __global__ __launch_bounds__(C * 4) void mix_bwd_split_kernel(const float* __restrict__ u, const float* __restrict__ g,
                                                               const float* __restrict__ M, float* __restrict__ gu,
                                                               float* __restrict__ part, int B, int HW, int accp) {
-    constexpr int T = C / 32, KS = C / 16, NT = C * 4, W = C / 16, FR = T * KS * 64;
-    constexpr int NTM = T * T / W;                         // gM tiles per wave (C = 64: 1)
+    constexpr int T = C / 32, KS = C / 16, NT = C * 4, W = C / 16, FR = T * KS * 64, TT = T * T;
+    // gM tiles (T x T of 32 x 32) over the W waves: whole tiles per wave where there are at least as many tiles as waves
+    // (C = 64: one each; C = 96: nine tiles on six waves), else (C = 32: one tile, two waves) the pixel contraction of a
+    // tile is cut into W / TT parts and the partial tiles meet in LDS at the end
+    constexpr int KPARTS = TT >= W ? 1 : W / TT;
+    constexpr int NTM = TT >= W ? (TT + W - 1) / W : 1;
     constexpr int IMG = C * kRow;                          // bytes of one bf16 image
     constexpr int PCS = C * 16 / NT;                       // 16-byte pieces of an fp32 tile per thread (4)
     static_assert(2 * IMG >= C * kRowF, "the result image fits in two piece images");
+    static_assert(KPARTS == 1 || (kPx / 16) % KPARTS == 0, "the pixel contraction splits evenly");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned short* frag = reinterpret_cast<unsigned short*>(smem);          // [3][FR][8] bf16 = 6*C*C bytes
     unsigned char* img_g = smem + (size_t)6 * C * C;                          // [3][C][kRow]
@@ -303,24 +308,27 @@ __global__ __launch_bounds__(C * 4) void mix_bwd_split_kernel(const float* __res
     for (int t = 0; t < NTM; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc_m[t][i] = 0.f;
-    const int per_sample = HW / kPx;
+    const int per_sample = (HW + kPx - 1) / kPx;           // the last tile of a sample may be ragged (HW a multiple of 4)
     const long total = (long)B * per_sample;
     float4 gq[PCS], uq[PCS];
     auto fetch = [&](long tile) __attribute__((always_inline)) {
         const size_t o = (size_t)(tile / per_sample) * C * HW;
         const int q0 = (int)(tile % per_sample) * kPx;
+        const int valid = HW - q0 < kPx ? HW - q0 : kPx;
 #pragma unroll
         for (int i = 0; i < PCS; ++i) {
             const int e = tid + i * NT, row = e >> 4, c4 = e & 15;
-            gq[i] = *reinterpret_cast<const float4*>(g + o + (size_t)row * HW + q0 + 4 * c4);
-            uq[i] = *reinterpret_cast<const float4*>(u + o + (size_t)row * HW + q0 + 4 * c4);
+            const int cc = 4 * c4 < valid ? 4 * c4 : 0;    // beyond the plane: re-read the tile's first piece, zeroed when deposited
+            gq[i] = *reinterpret_cast<const float4*>(g + o + (size_t)row * HW + q0 + cc);
+            uq[i] = *reinterpret_cast<const float4*>(u + o + (size_t)row * HW + q0 + cc);
         }
     };
-    auto deposit = [&](const float4 (&q)[PCS], unsigned char* img) __attribute__((always_inline)) {
+    auto deposit = [&](const float4 (&q)[PCS], unsigned char* img, int valid) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < PCS; ++i) {
             const int e = tid + i * NT, row = e >> 4, c4 = e & 15;
-            const float v[4] = {q[i].x, q[i].y, q[i].z, q[i].w};
+            const bool in = 4 * c4 < valid;
+            const float v[4] = {in ? q[i].x : 0.f, in ? q[i].y : 0.f, in ? q[i].z : 0.f, in ? q[i].w : 0.f};
             unsigned short p[3][4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) split3(v[j], p[0][j], p[1][j], p[2][j]);
@@ -332,30 +340,35 @@ __global__ __launch_bounds__(C * 4) void mix_bwd_split_kernel(const float* __res
     if ((long)blockIdx.x < total) fetch(blockIdx.x);
     for (long tile = blockIdx.x; tile < total; tile += gridDim.x) {
         const int b = (int)(tile / per_sample), p0 = (int)(tile % per_sample) * kPx;
+        const int valid = HW - p0 < kPx ? HW - p0 : kPx;
         __syncthreads();                                   // fragments built / previous tile's images consumed and stored
-        deposit(gq, img_g);
-        deposit(uq, img_u);
+        deposit(gq, img_g, valid);
+        deposit(uq, img_u, valid);
         __syncthreads();
         const long tn = tile + gridDim.x;
         if (tn < total) fetch(tn);                         // the next tile's loads fly during this tile's MFMAs
-        // gM: contraction over the 64 pixels of the tile, 16 per MFMA, six piece products
+        // gM: contraction over the 64 pixels of the tile (zeros beyond a ragged one), 16 per MFMA, six piece products
 #pragma unroll
-        for (int kp = 0; kp < kPx / 16; ++kp) {
+        for (int kq = 0; kq < kPx / 16 / KPARTS; ++kq) {
+            const int kp = KPARTS == 1 ? kq : kq * KPARTS + wave / TT;
 #pragma unroll
             for (int t = 0; t < NTM; ++t) {
-                const int tl = wave + W * t, it = tl / T, jt2 = tl % T;
-                v8bf a[3], bb[3];
+                const int tl = KPARTS == 1 ? wave + W * t : wave % TT;
+                if (tl < TT) {
+                    const int it = tl / T, jt2 = tl % T;
+                    v8bf a[3], bb[3];
 #pragma unroll
-                for (int s = 0; s < 3; ++s) {
-                    a[s] = row_operand(img_g + s * IMG, 32 * it + r, 16 * kp + 8 * h);
-                    bb[s] = row_operand(img_u + s * IMG, 32 * jt2 + r, 16 * kp + 8 * h);
+                    for (int s = 0; s < 3; ++s) {
+                        a[s] = row_operand(img_g + s * IMG, 32 * it + r, 16 * kp + 8 * h);
+                        bb[s] = row_operand(img_u + s * IMG, 32 * jt2 + r, 16 * kp + 8 * h);
+                    }
+                    acc_m[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bb[1], acc_m[t], 0, 0, 0);   // smallest terms first
+                    acc_m[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bb[2], acc_m[t], 0, 0, 0);
+                    acc_m[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], bb[0], acc_m[t], 0, 0, 0);
+                    acc_m[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bb[1], acc_m[t], 0, 0, 0);
+                    acc_m[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bb[0], acc_m[t], 0, 0, 0);
+                    acc_m[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bb[0], acc_m[t], 0, 0, 0);
                 }
-                acc_m[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bb[1], acc_m[t], 0, 0, 0);   // smallest terms first
-                acc_m[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bb[2], acc_m[t], 0, 0, 0);
-                acc_m[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], bb[0], acc_m[t], 0, 0, 0);
-                acc_m[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bb[1], acc_m[t], 0, 0, 0);
-                acc_m[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bb[0], acc_m[t], 0, 0, 0);
-                acc_m[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bb[0], acc_m[t], 0, 0, 0);
             }
         }
         // gu^T tile = g^T M, pieces of g against pieces of M
@@ -388,19 +401,39 @@ __global__ __launch_bounds__(C * 4) void mix_bwd_split_kernel(const float* __res
 #pragma unroll
         for (int i = 0; i < PCS; ++i) {
             const int e = tid + i * NT, row = e >> 4, c4 = e & 15;
-            *reinterpret_cast<float4*>(gu + (size_t)b * C * HW + (size_t)row * HW + p0 + 4 * c4) =
-                *reinterpret_cast<const float4*>(img_o + row * kRowF + 16 * c4);
+            if (4 * c4 < valid)
+                *reinterpret_cast<float4*>(gu + (size_t)b * C * HW + (size_t)row * HW + p0 + 4 * c4) =
+                    *reinterpret_cast<const float4*>(img_o + row * kRowF + 16 * c4);
         }
     }
     float* dst = part + (size_t)blockIdx.x * C * C;
+    if (KPARTS > 1) {                                      // partial tiles of the same gM tile: added in wave order through LDS
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(img_g);      // [W][16][64]
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) red[(wave * 16 + reg) * 64 + lane] = acc_m[0][reg];
+        __syncthreads();
+        if (wave < TT) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                float v = 0.f;
+#pragma unroll
+                for (int kpart = 0; kpart < KPARTS; ++kpart) v += red[((wave + TT * kpart) * 16 + reg) * 64 + lane];
+                acc_m[0][reg] = v;
+            }
+        }
+    }
 #pragma unroll
     for (int t = 0; t < NTM; ++t) {
-        const int tl = wave + W * t, it = tl / T, jt2 = tl % T;
+        const int tl = KPARTS == 1 ? wave + W * t : wave;
+        if (tl < TT && (KPARTS == 1 || wave < TT)) {
+            const int it = tl / T, jt2 = tl % T;
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int i = 32 * it + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-            float* o = dst + i * C + 32 * jt2 + r;
-            *o = accp ? *o + acc_m[t][reg] : acc_m[t][reg];
+            for (int reg = 0; reg < 16; ++reg) {
+                const int i = 32 * it + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                float* o = dst + i * C + 32 * jt2 + r;
+                *o = accp ? *o + acc_m[t][reg] : acc_m[t][reg];
+            }
         }
     }
 }
@@ -440,18 +473,22 @@ void launch_split(const void* u, const void* g, const float* M, void* gu, float*
 
 }  // namespace
 
-// fp32 tensors through the bf16 matrix cores, three pieces per operand (C = 64, HW a multiple of 64)
+// fp32 tensors through the bf16 matrix cores, three pieces per operand: C = 32, 64 or 96 (at C = 128 the three fragment
+// tables of M and the six piece images do not fit in LDS together), planes of any multiple of 4 pixels (the last 64-pixel
+// tile of a sample may be ragged)
 bool mix_split_ok(int C, int HW) {
-    return C == 64 && (HW % kPx) == 0 && getenv("PDE_MIX_NO_SPLIT") == nullptr;
+    return (C == 32 || C == 64 || C == 96) && (HW % 4) == 0 && HW >= 4 && getenv("PDE_MIX_NO_SPLIT") == nullptr;
 }
 int mix_split_splits(int B, int C, int HW) {
-    const long tiles = (long)B * (HW / kPx);
-    const long want = 512;                                 // two resident workgroups per CU (78 KB of LDS each)
+    const long tiles = (long)B * ((HW + kPx - 1) / kPx);
+    const long want = C == 32 ? 1024 : (C == 64 ? 512 : 256);   // resident workgroups: 33 / 78 / 138 KB of LDS each
     return (int)(tiles < want ? tiles : want);
 }
 int mix_split_backward(int B, int C, int HW, const void* u, const void* g, const float* M, void* gu, float* part, int nsplit,
                        int accp, hipStream_t st) {
-    launch_split<64>(u, g, M, gu, part, B, HW, nsplit, accp, st);
+    if (C == 32) launch_split<32>(u, g, M, gu, part, B, HW, nsplit, accp, st);
+    else if (C == 64) launch_split<64>(u, g, M, gu, part, B, HW, nsplit, accp, st);
+    else launch_split<96>(u, g, M, gu, part, B, HW, nsplit, accp, st);
     return check_launch();
 }
 

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import threading
+import time
 import weakref
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
@@ -256,14 +257,19 @@ class _KmaxOwned:
         self.host, self.event = host, event
 
 
-def _wait_event(ev, spins=4000):
-    """Wait for an event that is expected within microseconds (the factorisation kernel right behind the forward's
-    launch): poll it before blocking — a blocking hipEventSynchronize costs the host ~100-150 us to wake up, more than
-    the whole backward of a small layer takes to launch."""
+def _wait_event(ev, budget=0.02):
+    """Wait for an event that is expected within microseconds of the device reaching the factorisation kernel: poll it
+    before blocking — a blocking hipEventSynchronize costs the host ~100-150 us to wake up, more than the whole backward
+    of a small layer takes to launch.  The poll is bounded by time (in a device-bound loop the host arrives while the
+    previous step's backward is still running), not by a number of queries."""
     q = ev.query
-    for _ in range(spins):
-        if q():
-            return
+    t0 = time.perf_counter()
+    while True:
+        for _ in range(64):
+            if q():
+                return
+        if time.perf_counter() - t0 > budget:
+            break
     ev.synchronize()
 
 

@@ -272,14 +272,16 @@ def test_channel_mix_vs_fp64(C, HW):
     assert G.rel_err(Md.grad.cpu(), M64.grad) <= TOL
 
 
-@pytest.mark.parametrize("B,HW,scale", [(5, 1024, 0.1), (64, 1024, 0.3), (7, 64, 1.0), (1, 4096, 0.05)])
-def test_channel_mix_three_piece_products(B, HW, scale):
-    """fp32 tensors at C = 64 run the operator's backward on the bf16 matrix cores with every operand as three bf16 pieces
-    (pde_mix_bf16.hip: mix_bwd_split_kernel).  That must be fp32 arithmetic to the last bits, not bf16 arithmetic: against
-    fp64, with six decades of dynamic range across the channels of the incoming gradient, tighter than the 1e-5 of the
-    other paths (measured 6-9e-8 and 2-4e-7; torch's own fp32 matmul is at 7e-8 and 3-7e-7)."""
+@pytest.mark.parametrize("C,B,HW,scale", [(64, 5, 1024, 0.1), (64, 64, 1024, 0.3), (64, 7, 64, 1.0), (64, 1, 4096, 0.05),
+                                          (32, 5, 784, 0.1), (32, 64, 1024, 0.3), (32, 3, 16, 1.0), (96, 5, 1024, 0.1),
+                                          (96, 3, 196, 0.3), (64, 5, 784, 0.1), (96, 2, 4, 0.1)])
+def test_channel_mix_three_piece_products(C, B, HW, scale):
+    """fp32 tensors at C = 32, 64, 96 run the operator's backward on the bf16 matrix cores with every operand as three bf16
+    pieces (pde_mix_bf16.hip: mix_bwd_split_kernel; planes of any multiple of four pixels — 28 x 28 = 784 leaves a ragged
+    last tile).  That must be fp32 arithmetic to the last bits, not bf16 arithmetic: against fp64, with six decades of
+    dynamic range across the channels of the incoming gradient, tighter than the 1e-5 of the other paths (measured 6-9e-8
+    and 2-4e-7; torch's own fp32 matmul is at 7e-8 and 3-7e-7)."""
     import cnn_with_pde_amd as P
-    C = 64
     g = torch.Generator().manual_seed(1000 + B)
     u = torch.randn(B, C, HW, generator=g)
     M = torch.eye(C) + scale * torch.randn(C, C, generator=g)
