@@ -404,33 +404,41 @@ __global__ __launch_bounds__(kRhStripThreads) void rh_bwd_strip_kernel(RhBwdArgs
 // boundary is the hand-off: an in-kernel one (the workgroup whose ticket comes last finishes the strip) was built and
 // measured — with the agent-scope release / acquire the non-coherent per-XCD L2s need, it gave back all but 3 % of the
 // gain (254 us per forward + backward against 261; 117 us per PRODUCT with __threadfence() in every thread).
-constexpr int kS32Threads = 256, kS32Cols = 32, kS32Bk = 32, kS32Lda = kS32Bk + 4, kS32LdN = kS32Cols + 4;
-constexpr int kS32TileFloats = 4 * 64 * 16;              // one partial tile: [wave][4][lane] float4
+constexpr int kS32Cols = 32, kS32Bk = 32, kS32Lda = kS32Bk + 4, kS32LdN = kS32Cols + 4;
+// WV waves per workgroup, 32 batch rows each: 4 (up to 128 rows) or 2 (up to 64, the reference's batch: half the rows of the
+// four-wave tile would be padding there); one partial tile is [wave][4][lane] float4
+constexpr int tile32_floats(int wv) { return wv * 64 * 16; }
 
-template <bool NT>
+template <bool NT, int WV>
 __device__ __forceinline__ void strip32_gemm(const float* __restrict__ X, int B, int klen, int ldx, const float* __restrict__ W,
                                              int ldw, int n0, f32x16& acc, float* As, float* Ws) {
     constexpr int BK = kS32Bk, LDA = kS32Lda, C4 = BK / 4;
-    constexpr int ASZ = kRhRows32 * LDA, WSZ = NT ? kS32Cols * LDA : BK * kS32LdN;
-    constexpr int APT = kRhRows32 * C4 / kS32Threads;    // X-slab float4 per thread (4); the W slab is one float4 per thread
-    static_assert(kS32Cols * BK / 4 == kS32Threads, "one operand float4 per thread");
+    constexpr int ROWS = WV * 32, THREADS = WV * 64;
+    constexpr int ASZ = ROWS * LDA, WSZ = NT ? kS32Cols * LDA : BK * kS32LdN;
+    constexpr int APT = ROWS * C4 / THREADS;             // X-slab float4 per thread (4)
+    constexpr int WPT = kS32Cols * BK / 4 / THREADS;      // W-slab float4 per thread (1 or 2)
+    static_assert(WPT * THREADS == kS32Cols * BK / 4, "whole operand float4s per thread");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, jj = lane & 31, kh = lane >> 5;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    float4 pa[APT], pw;
+    float4 pa[APT], pw[WPT];
     auto fetch = [&](int k0) __attribute__((always_inline)) {
 #pragma unroll
         for (int m = 0; m < APT; ++m) {
-            const int f = tid + kS32Threads * m, row = f / C4, c4 = f % C4;
+            const int f = tid + THREADS * m, row = f / C4, c4 = f % C4;
             const int rc = row < B ? row : B - 1;         // rows beyond the batch: re-read the last one, zeroed when staged
             pa[m] = *reinterpret_cast<const float4*>(X + (size_t)rc * ldx + k0 + 4 * c4);
         }
-        if (NT) {
-            const int row = tid / C4, c4 = tid % C4;      // feature n0 + row, k0 + 4 c4
-            pw = *reinterpret_cast<const float4*>(W + (size_t)(n0 + row) * ldw + k0 + 4 * c4);
-        } else {
-            const int row = tid / (kS32Cols / 4), c4 = tid % (kS32Cols / 4);   // k0 + row, features n0 + 4 c4
-            pw = *reinterpret_cast<const float4*>(W + (size_t)(k0 + row) * ldw + n0 + 4 * c4);
+#pragma unroll
+        for (int m = 0; m < WPT; ++m) {
+            const int f = tid + THREADS * m;
+            if (NT) {
+                const int row = f / C4, c4 = f % C4;      // feature n0 + row, k0 + 4 c4
+                pw[m] = *reinterpret_cast<const float4*>(W + (size_t)(n0 + row) * ldw + k0 + 4 * c4);
+            } else {
+                const int row = f / (kS32Cols / 4), c4 = f % (kS32Cols / 4);   // k0 + row, features n0 + 4 c4
+                pw[m] = *reinterpret_cast<const float4*>(W + (size_t)(k0 + row) * ldw + n0 + 4 * c4);
+            }
         }
     };
     auto stage = [&](int buf) __attribute__((always_inline)) {
@@ -438,15 +446,19 @@ __device__ __forceinline__ void strip32_gemm(const float* __restrict__ X, int B,
         float* Wb = Ws + buf * WSZ;
 #pragma unroll
         for (int m = 0; m < APT; ++m) {
-            const int f = tid + kS32Threads * m, row = f / C4, c4 = f % C4;
+            const int f = tid + THREADS * m, row = f / C4, c4 = f % C4;
             *reinterpret_cast<float4*>(A + row * LDA + 4 * c4) = row < B ? pa[m] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        if (NT) {
-            const int row = tid / C4, c4 = tid % C4;
-            *reinterpret_cast<float4*>(Wb + row * LDA + 4 * c4) = pw;
-        } else {
-            const int row = tid / (kS32Cols / 4), c4 = tid % (kS32Cols / 4);
-            *reinterpret_cast<float4*>(Wb + row * kS32LdN + 4 * c4) = pw;
+#pragma unroll
+        for (int m = 0; m < WPT; ++m) {
+            const int f = tid + THREADS * m;
+            if (NT) {
+                const int row = f / C4, c4 = f % C4;
+                *reinterpret_cast<float4*>(Wb + row * LDA + 4 * c4) = pw[m];
+            } else {
+                const int row = f / (kS32Cols / 4), c4 = f % (kS32Cols / 4);
+                *reinterpret_cast<float4*>(Wb + row * kS32LdN + 4 * c4) = pw[m];
+            }
         }
     };
     fetch(0);
@@ -484,13 +496,13 @@ __device__ __forceinline__ void strip32_gemm(const float* __restrict__ X, int B,
 __device__ __forceinline__ int acc32_row(int wave, int r, int kh) { return wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh; }
 
 // partial tile of (strip, split): [wave][4][lane] float4, lane-major, so that stores and loads are whole 1 KB rows
-__device__ __forceinline__ void strip32_store(const f32x16& acc, float* part, int strip, int split, int S) {
+__device__ __forceinline__ void strip32_store(const f32x16& acc, float* part, int strip, int split, int S, int tile_floats) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    f32x4* mine = reinterpret_cast<f32x4*>(part + ((size_t)strip * S + split) * kS32TileFloats) + wave * 4 * 64 + lane;
+    f32x4* mine = reinterpret_cast<f32x4*>(part + ((size_t)strip * S + split) * tile_floats) + wave * 4 * 64 + lane;
 #pragma unroll
     for (int q = 0; q < 4; ++q) mine[q * 64] = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
 }
-// ---- epilogue launches: one workgroup per (strip, column quarter) = 128 rows x 8 columns, thread t = ((w * 4 + q) * 2
+// ---- epilogue launches: one workgroup per (strip, column quarter) = 128 (64) rows x 8 columns, thread t = ((w * 4 + q) * 2
 // + kh) * 8 + j holds the float4 of tile wave w, register quad q, lane kh * 32 + 8 * quarter + j: rows
 // 32 w + 8 q + 4 kh + (0..3) of column 8 * quarter + j.  (One workgroup per strip — 96 of them — took 8-11 us per
 // launch: too few loads in flight.)
@@ -506,13 +518,14 @@ struct Epi32 {
 // the S partial tiles of a strip added in split order (the loads of four tiles in flight together)
 __device__ __forceinline__ f32x4 strip32_sum(const float* part, int strip, int quarter, int S, const Epi32& e) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int tile_floats = (int)(blockDim.x >> 6) * 64 * 16;
     const size_t at = (size_t)(e.w * 4 + e.q) * 64 + e.kh * 32 + 8 * quarter + e.j;
     for (int s0 = 0; s0 < S; s0 += 4) {
         f32x4 v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int sc = s0 + i < S ? s0 + i : S - 1;
-            v[i] = reinterpret_cast<const f32x4*>(part + ((size_t)strip * S + sc) * kS32TileFloats)[at];
+            v[i] = reinterpret_cast<const f32x4*>(part + ((size_t)strip * S + sc) * tile_floats)[at];
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -529,26 +542,27 @@ __device__ __forceinline__ float column_total8(float v, float* red) {
     __syncthreads();
     if ((t & 63) < 8) red[(t >> 6) * 8 + (t & 7)] = v;
     __syncthreads();
-    return (red[t & 7] + red[8 + (t & 7)]) + (red[16 + (t & 7)] + red[24 + (t & 7)]);
+    const float lo = red[t & 7] + red[8 + (t & 7)];
+    return blockDim.x > 128 ? lo + (red[16 + (t & 7)] + red[24 + (t & 7)]) : lo;      // four waves or two
 }
 
 struct RhPartArgs { const float* X; const float* W; float* part; int B, D, S; };
 
 // partial products of a strip: blockIdx.y = slice of the contraction
-template <bool NT>
-__global__ __launch_bounds__(kS32Threads) void rh_part32_kernel(RhPartArgs a) {
+template <bool NT, int WV>
+__global__ __launch_bounds__(WV * 64) void rh_part32_kernel(RhPartArgs a) {
     extern __shared__ __attribute__((aligned(16))) float rh_smem[];
-    float* As = rh_smem;                                                 // [2][128][LDA]
-    float* Ws = As + 2 * kRhRows32 * kS32Lda;                            // [2][32][LDA] / [2][BK][LdN]
+    float* As = rh_smem;                                                 // [2][32 WV][LDA]
+    float* Ws = As + 2 * WV * 32 * kS32Lda;                              // [2][32][LDA] / [2][BK][LdN]
     const int strip = blockIdx.x, split = blockIdx.y, n0 = strip * kS32Cols;
     const int klen = a.D / a.S, kb = split * klen;
     f32x16 acc;
-    strip32_gemm<NT>(a.X + kb, a.B, klen, a.D, NT ? a.W + kb : a.W + (size_t)kb * a.D, a.D, n0, acc, As, Ws);
-    strip32_store(acc, a.part, strip, split, a.S);
+    strip32_gemm<NT, WV>(a.X + kb, a.B, klen, a.D, NT ? a.W + kb : a.W + (size_t)kb * a.D, a.D, n0, acc, As, Ws);
+    strip32_store(acc, a.part, strip, split, a.S, tile32_floats(WV));
 }
 
 // P = sum of the partial tiles; BatchNorm1d over the batch (cifar_2version.py:201, 214-215), activation (:216)
-__global__ __launch_bounds__(kS32Threads) void rh_fwd32_epi_kernel(RhFwdArgs a, const float* part, int S) {
+__global__ __launch_bounds__(256) void rh_fwd32_epi_kernel(RhFwdArgs a, const float* part, int S) {
     __shared__ float red[32];
     const Epi32 e(blockIdx.x, blockIdx.y);
     f32x4 acc = strip32_sum(part, blockIdx.x, blockIdx.y, S, e);
@@ -587,7 +601,7 @@ __global__ __launch_bounds__(kS32Threads) void rh_fwd32_epi_kernel(RhFwdArgs a, 
 }
 
 // out = base + scale * (sum of the partial tiles)
-__global__ __launch_bounds__(kS32Threads) void rh_axpy32_epi_kernel(RhAxpyArgs a, const float* part, int S) {
+__global__ __launch_bounds__(256) void rh_axpy32_epi_kernel(RhAxpyArgs a, const float* part, int S) {
     const Epi32 e(blockIdx.x, blockIdx.y);
     const f32x4 acc = strip32_sum(part, blockIdx.x, blockIdx.y, S, e);
 #pragma unroll
@@ -601,7 +615,7 @@ __global__ __launch_bounds__(kS32Threads) void rh_axpy32_epi_kernel(RhAxpyArgs a
 }
 
 // dH = scale * (sum of the partial tiles of G K^T); through the activation and the BatchNorm -> dP, dgamma, dbeta
-__global__ __launch_bounds__(kS32Threads) void rh_bwd32_epi_kernel(RhBwdArgs a, const float* part, int S) {
+__global__ __launch_bounds__(256) void rh_bwd32_epi_kernel(RhBwdArgs a, const float* part, int S) {
     __shared__ float red[32];
     const Epi32 e(blockIdx.x, blockIdx.y);
     f32x4 acc = strip32_sum(part, blockIdx.x, blockIdx.y, S, e);
@@ -895,29 +909,40 @@ int launch_strip(KERN kern, const ARGS& a, int D, int row_blocks, hipStream_t st
 
 bool rh_dims_ok(int B, int D) { return B >= 1 && D >= 64 && (D % 64) == 0; }
 
-// the split of a 32-column strip's contraction: a power of two (2..8), slices of whole 32-wide slabs and at least two of
-// them, at most ~4 workgroups per CU; 0 = this batch / width keeps the 16-column kernels
+// Waves of a 32-column strip workgroup for this batch, and the split of a strip's contraction: a power of two (2..8),
+// slices of whole 32-wide slabs and at least two of them, three workgroups per CU at D = 3072;
+// 0 = this batch / width keeps the 16-column kernels
+int rh_waves32(int B) { return B <= 64 ? 2 : 4; }
 int rh_split32(int B, int D) {
     static const bool off = getenv("PDE_RH_NO_STRIP32") != nullptr;
     if (off || B > kRhRows32) return 0;
-    int S = 8;
-    while (S > 1 && (D % (S * 2 * kS32Bk) != 0 || (D / kS32Cols) * S > 1024)) S >>= 1;
+    const int wv = rh_waves32(B);
+    int S = 8;                                           // (two waves: 16 slices measured slower, 171 us against 158 per layer)
+    static const int forced = getenv("PDE_RH_SPLIT") ? atoi(getenv("PDE_RH_SPLIT")) : 0;     // diagnostics: the starting split
+    if (forced >= 2 && forced <= 16 && (forced & (forced - 1)) == 0) S = forced;
+    while (S > 1 && (D % (S * 2 * kS32Bk) != 0 || (D / kS32Cols) * S > (wv == 2 ? 2048 : 1024))) S >>= 1;
     return S >= 2 ? S : 0;
 }
-size_t rh_split32_bytes(int D, int S) { return S < 2 ? 0 : (size_t)(D / kS32Cols) * S * kS32TileFloats * sizeof(float); }
-constexpr size_t strip32_lds() {
-    return (size_t)(2 * kRhRows32 * kS32Lda + 2 * (kS32Cols * kS32Lda > kS32Bk * kS32LdN ? kS32Cols * kS32Lda : kS32Bk * kS32LdN))
+size_t rh_split32_bytes(int B, int D, int S) {
+    return S < 2 ? 0 : (size_t)(D / kS32Cols) * S * tile32_floats(rh_waves32(B)) * sizeof(float);
+}
+constexpr size_t strip32_lds(int wv) {
+    return (size_t)(2 * wv * 32 * kS32Lda + 2 * (kS32Cols * kS32Lda > kS32Bk * kS32LdN ? kS32Cols * kS32Lda : kS32Bk * kS32LdN))
            * sizeof(float);
 }
 // partial products X W^T (NT) or X W (NN) of every strip into `ws`
-template <bool NT>
-int launch_part32(const float* X, const float* W, int B, int D, int S, void* ws, hipStream_t st) {
+template <bool NT, int WV>
+int launch_part32_wv(const float* X, const float* W, int B, int D, int S, void* ws, hipStream_t st) {
     static unsigned long long configured = 0;
-    if (ensure_dynamic_lds(reinterpret_cast<const void*>(rh_part32_kernel<NT>), (int)strip32_lds(), configured) != PDE_OK)
+    if (ensure_dynamic_lds(reinterpret_cast<const void*>(rh_part32_kernel<NT, WV>), (int)strip32_lds(WV), configured) != PDE_OK)
         return PDE_E_LAUNCH;
     RhPartArgs a{X, W, static_cast<float*>(ws), B, D, S};
-    hipLaunchKernelGGL(rh_part32_kernel<NT>, dim3(D / kS32Cols, S), dim3(kS32Threads), strip32_lds(), st, a);
+    hipLaunchKernelGGL((rh_part32_kernel<NT, WV>), dim3(D / kS32Cols, S), dim3(WV * 64), strip32_lds(WV), st, a);
     return check_launch();
+}
+template <bool NT>
+int launch_part32(const float* X, const float* W, int B, int D, int S, void* ws, hipStream_t st) {
+    return rh_waves32(B) == 2 ? launch_part32_wv<NT, 2>(X, W, B, D, S, ws, st) : launch_part32_wv<NT, 4>(X, W, B, D, S, ws, st);
 }
 
 }  // namespace
@@ -931,7 +956,7 @@ int pde_sym_layer_supported(int32_t B, int32_t D) { return rh_dims_ok(B, D) ? 1 
 
 size_t pde_sym_layer_workspace_bytes(int32_t B, int32_t D) {
     if (!rh_dims_ok(B, D)) return 0;
-    return rh_split32_bytes(D, rh_split32(B, D));
+    return rh_split32_bytes(B, D, rh_split32(B, D));
 }
 
 int pde_sym_layer_forward(int32_t B, int32_t D, int32_t act, int32_t training, const float* X, const float* K,
@@ -948,15 +973,15 @@ int pde_sym_layer_forward(int32_t B, int32_t D, int32_t act, int32_t training, c
     int rc;
     const int S = workspace ? rh_split32(B, D) : 0;       // no workspace: the 16-column kernels (one workgroup per strip)
     if (S >= 2) {
-        if (workspace_bytes < rh_split32_bytes(D, S) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return PDE_E_WORKSPACE;
+        if (workspace_bytes < rh_split32_bytes(B, D, S) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return PDE_E_WORKSPACE;
         const float* part = static_cast<const float*>(workspace);
         rc = launch_part32<true>(X, K, B, D, S, workspace, st);
         if (rc != PDE_OK) return rc;
-        hipLaunchKernelGGL(rh_fwd32_epi_kernel, dim3(D / kS32Cols, 4), dim3(kS32Threads), 0, st, f, part, S);
+        hipLaunchKernelGGL(rh_fwd32_epi_kernel, dim3(D / kS32Cols, 4), dim3(64 * rh_waves32(B)), 0, st, f, part, S);
         rc = launch_part32<false>(H, K, B, D, S, workspace, st);
         if (rc != PDE_OK) return rc;
         RhAxpyArgs x{H, K, base, out, B, D, scale};
-        hipLaunchKernelGGL(rh_axpy32_epi_kernel, dim3(D / kS32Cols, 4), dim3(kS32Threads), 0, st, x, part, S);
+        hipLaunchKernelGGL(rh_axpy32_epi_kernel, dim3(D / kS32Cols, 4), dim3(64 * rh_waves32(B)), 0, st, x, part, S);
         return check_launch();
     }
     if (nblk == 1) {                                      // the whole batch in one strip workgroup: statistics as epilogue
@@ -987,15 +1012,15 @@ int pde_sym_layer_backward(int32_t B, int32_t D, int32_t act, int32_t training, 
     int rc;
     const int S = workspace ? rh_split32(B, D) : 0;
     if (S >= 2) {
-        if (workspace_bytes < rh_split32_bytes(D, S) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return PDE_E_WORKSPACE;
+        if (workspace_bytes < rh_split32_bytes(B, D, S) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return PDE_E_WORKSPACE;
         const float* part = static_cast<const float*>(workspace);
         rc = launch_part32<true>(g_out, K, B, D, S, workspace, st);
         if (rc != PDE_OK) return rc;
-        hipLaunchKernelGGL(rh_bwd32_epi_kernel, dim3(D / kS32Cols, 4), dim3(kS32Threads), 0, st, b, part, S);
+        hipLaunchKernelGGL(rh_bwd32_epi_kernel, dim3(D / kS32Cols, 4), dim3(64 * rh_waves32(B)), 0, st, b, part, S);
         rc = launch_part32<false>(dP, K, B, D, S, workspace, st);
         if (rc != PDE_OK) return rc;
         RhAxpyArgs x32{dP, K, nullptr, gX, B, D, 1.0f};
-        hipLaunchKernelGGL(rh_axpy32_epi_kernel, dim3(D / kS32Cols, 4), dim3(kS32Threads), 0, st, x32, part, S);
+        hipLaunchKernelGGL(rh_axpy32_epi_kernel, dim3(D / kS32Cols, 4), dim3(64 * rh_waves32(B)), 0, st, x32, part, S);
         rc = check_launch();
     } else if (nblk == 1) {
         rc = launch_strip(rh_bwd_strip_kernel<1>, b, D, 1, st);
