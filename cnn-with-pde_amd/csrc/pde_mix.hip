@@ -71,7 +71,10 @@ __global__ __launch_bounds__(256) void mix_gm_kernel(const IO* __restrict__ u, c
     const int split = blockIdx.y;
     const int tid = threadIdx.x;
     const int oi = (tid / 16) * 2, oj = (tid % 16) * 2;      // 2x2 outputs per thread
-    float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
+    // double accumulators: a thread adds thousands of products here, and at small C the whole sum is a few numbers that
+    // may cancel (the 1 x 1 coupling gradient of a C = 1 layer was 3.6e-5 from the fp64 value where torch's pairwise fp32
+    // sum is at 4e-7; a seeded walk of round 4 drew it); the products of two floats are exact in double
+    double a00 = 0.0, a01 = 0.0, a10 = 0.0, a11 = 0.0;
     const int chunks_per_b = (HW + kK - 1) / kK;
     const long total = (long)B * chunks_per_b;
     for (long ch = split; ch < total; ch += nsplit) {
@@ -90,15 +93,15 @@ __global__ __launch_bounds__(256) void mix_gm_kernel(const IO* __restrict__ u, c
         for (int k = 0; k < kK; ++k) {
             const float g0 = sg[k][oi], g1 = sg[k][oi + 1];
             const float u0 = su[k][oj], u1 = su[k][oj + 1];
-            a00 = fmaf(g0, u0, a00); a01 = fmaf(g0, u1, a01);
-            a10 = fmaf(g1, u0, a10); a11 = fmaf(g1, u1, a11);
+            a00 += (double)g0 * (double)u0; a01 += (double)g0 * (double)u1;
+            a10 += (double)g1 * (double)u0; a11 += (double)g1 * (double)u1;
         }
         __syncthreads();
     }
     float* dst = part + (size_t)split * C * C;
     const int i = ti * kT + oi, j = tj * kT + oj;
     auto put = [&](int ii, int jj2, float v) { if (ii < C && jj2 < C) dst[ii * C + jj2] = acc ? dst[ii * C + jj2] + v : v; };
-    put(i, j, a00); put(i, j + 1, a01); put(i + 1, j, a10); put(i + 1, j + 1, a11);
+    put(i, j, (float)a00); put(i, j + 1, (float)a01); put(i + 1, j, (float)a10); put(i + 1, j + 1, (float)a11);
 }
 
 __global__ __launch_bounds__(256) void mix_gm_reduce_kernel(const float* __restrict__ part, float* __restrict__ gM,
