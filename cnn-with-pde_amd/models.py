@@ -226,7 +226,8 @@ class CIFAR10PDENoConv(nn.Module):
 class SymmetricLayer(nn.Module):
     """cifar_2version.py:190-220 (Ruthotto & Haber): F(Y) = -K^T act(BN(K Y)) on the flattened image, K a dense
     (C*H*W)^2 matrix initialised near the identity.  On the GPU both products, the BatchNorm1d over the batch and the
-    activation run as two launches on the fp32 matrix cores (``functional.sym_layer``, pde_rh.hip — SURVEY §8f-4);
+    activation run on the fp32 matrix cores (``functional.sym_layer``, pde_rh.hip — SURVEY §8f-4: up to 128 rows each product
+    as 32-column strips with the contraction split over workgroups plus a small epilogue launch);
     ``residual(base, X, scale)`` is the fused update ``base + scale * (act(BN(X K^T)) K)`` the two blocks below are made
     of.  ``fused = False`` (or a shape the kernels do not take, or autocast) is plain torch, as in the reference."""
 
