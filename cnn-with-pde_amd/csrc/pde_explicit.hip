@@ -215,7 +215,7 @@ __device__ __forceinline__ void lap0_rows(const float4 (&c)[R], float4 (&lp)[R],
 template <typename IO, int R, int W4>
 __global__ __launch_bounds__(256) void explicit5_fwd_wave(const IO* __restrict__ u, const float* __restrict__ alpha,
                                                           const float* __restrict__ scale, IO* __restrict__ out,
-                                                          IO* __restrict__ states, int nplanes, int C, int num_steps,
+                                                          float* __restrict__ states, int nplanes, int C, int num_steps,
                                                           float dt, float eps, float maxc, float relax) {
     constexpr int W = 4 * W4, H = R * (64 / W4);
     const int lane = threadIdx.x & 63;
@@ -239,14 +239,12 @@ __global__ __launch_bounds__(256) void explicit5_fwd_wave(const IO* __restrict__
             { const float v = s * cur[i].z; const float nw = v + a * (s * lp[i].z); cur[i].z = cur[i].z + relax * (nw - cur[i].z); }
             { const float v = s * cur[i].w; const float nw = v + a * (s * lp[i].w); cur[i].w = cur[i].w + relax * (nw - cur[i].w); }
         }
-        if (step + 1 < num_steps && states != nullptr) {          // inputs of the later steps, for the backward
-            IO* sp = states + (size_t)step * nplanes * H * W;
+        // inputs of the later steps, for the backward: kept in fp32 whatever the tensors' type (with bf16 states the
+        // alpha-gradient — a sum over the whole batch that cancels to a few units — was a quarter off on a drawn case)
+        if (step + 1 < num_steps && states != nullptr) {
+            float* sp = states + (size_t)step * nplanes * H * W;
 #pragma unroll
-            for (int i = 0; i < R; ++i) V4<IO>::st(sp + off + (size_t)i * W, cur[i]);
-            if (sizeof(IO) < 4) {                                 // later steps continue from the ROUNDED state,
-#pragma unroll
-                for (int i = 0; i < R; ++i) cur[i] = V4<IO>::round(cur[i]);   // as the backward will read it
-            }
+            for (int i = 0; i < R; ++i) V4<float>::st(sp + off + (size_t)i * W, cur[i]);
         }
     }
 #pragma unroll
@@ -261,7 +259,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // backward of num_steps steps: g walks back through the steps in registers; u_{k-1} (the input of step k) is the
 // layer input for k = 1 and states[k-2] otherwise
 template <typename IO, int R, int W4>
-__global__ __launch_bounds__(256) void explicit5_bwd_wave(const IO* __restrict__ u, const IO* __restrict__ states,
+__global__ __launch_bounds__(256) void explicit5_bwd_wave(const IO* __restrict__ u, const float* __restrict__ states,
                                                           const IO* __restrict__ g, const float* __restrict__ alpha,
                                                           const float* __restrict__ scale, IO* __restrict__ gu,
                                                           float* __restrict__ part, int nplanes, int C, int num_steps,
@@ -280,11 +278,11 @@ __global__ __launch_bounds__(256) void explicit5_bwd_wave(const IO* __restrict__
     for (int i = 0; i < R; ++i) cg4[i] = V4<IO>::ld_once(g + off + (size_t)i * W);
     float p1 = 0.f, p2 = 0.f;                                     // sum g*u, sum Lap0(g)*u over all steps
     for (int step = num_steps; step >= 1; --step) {
-        const IO* up = (step == 1) ? u : states + (size_t)(step - 2) * nplanes * H * W;
+        const float* sp = states + (size_t)(step >= 2 ? step - 2 : 0) * nplanes * H * W;
         lap0_rows<R, W4>(cg4, lg, cg, rg);
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-            const float4 cu = V4<IO>::ld_once(up + off + (size_t)i * W);
+            const float4 cu = (step == 1) ? V4<IO>::ld_once(u + off + (size_t)i * W) : V4<float>::ld_once(sp + off + (size_t)i * W);
             p1 += cg4[i].x * cu.x + cg4[i].y * cu.y + cg4[i].z * cu.z + cg4[i].w * cu.w;
             p2 += lg[i].x * cu.x + lg[i].y * cu.y + lg[i].z * cu.z + lg[i].w * cu.w;
             cg4[i].x = (1.f - relax) * cg4[i].x + relax * s * (cg4[i].x + a * lg[i].x);
@@ -304,7 +302,7 @@ __global__ __launch_bounds__(256) void explicit5_bwd_wave(const IO* __restrict__
 bool wave_plane_ok(int H, int W) { return (H == 64 && W == 64) || (H == 32 && W == 32) || (H == 16 && W == 16); }
 
 template <typename IO>
-void launch_fwd_wave(int H, const IO* u, const float* alpha, const float* scale, IO* out, IO* states, int nplanes, int C,
+void launch_fwd_wave(int H, const IO* u, const float* alpha, const float* scale, IO* out, float* states, int nplanes, int C,
                      int num_steps, float dt, float eps, float maxc, float relax, hipStream_t st) {
     const dim3 grid((nplanes + 3) / 4), block(256);
     if (H == 64) hipLaunchKernelGGL((explicit5_fwd_wave<IO, 16, 16>), grid, block, 0, st, u, alpha, scale, out, states, nplanes, C, num_steps, dt, eps, maxc, relax);
@@ -312,7 +310,7 @@ void launch_fwd_wave(int H, const IO* u, const float* alpha, const float* scale,
     else hipLaunchKernelGGL((explicit5_fwd_wave<IO, 1, 4>), grid, block, 0, st, u, alpha, scale, out, states, nplanes, C, num_steps, dt, eps, maxc, relax);
 }
 template <typename IO>
-void launch_bwd_wave(int H, const IO* u, const IO* states, const IO* g, const float* alpha, const float* scale, IO* gu,
+void launch_bwd_wave(int H, const IO* u, const float* states, const IO* g, const float* alpha, const float* scale, IO* gu,
                      float* part, int nplanes, int C, int num_steps, float dt, float eps, float maxc, float relax,
                      hipStream_t st) {
     const dim3 grid((nplanes + 3) / 4), block(256);
@@ -511,7 +509,7 @@ int pde_explicit5_forward(int32_t B, int32_t C, int32_t H, int32_t W, int32_t io
             launch_fwd_wave<float>(H, (const float*)u, alpha_base, channel_scaling, (float*)out, (float*)states, nplanes, C,
                                    num_steps, dt, eps, max_coeff, relax, st);
         else
-            launch_fwd_wave<bf16e>(H, (const bf16e*)u, alpha_base, channel_scaling, (bf16e*)out, (bf16e*)states, nplanes, C,
+            launch_fwd_wave<bf16e>(H, (const bf16e*)u, alpha_base, channel_scaling, (bf16e*)out, (float*)states, nplanes, C,
                                    num_steps, dt, eps, max_coeff, relax, st);
         return check_launch();
     }
@@ -529,6 +527,8 @@ int pde_explicit5_forward(int32_t B, int32_t C, int32_t H, int32_t W, int32_t io
     }
     return check_launch();
 }
+
+int pde_explicit5_states_fp32(int32_t H, int32_t W) { return wave_plane_ok(H, W) ? 1 : 0; }
 
 size_t pde_explicit5_backward_workspace_bytes(int32_t B, int32_t C, int32_t H, int32_t W, int32_t io_dtype,
                                               int32_t num_steps) {
@@ -557,7 +557,7 @@ int pde_explicit5_backward(int32_t B, int32_t C, int32_t H, int32_t W, int32_t i
             launch_bwd_wave<float>(H, (const float*)u, (const float*)states, (const float*)gout, alpha_base, channel_scaling,
                                    (float*)gu, part, nplanes, C, num_steps, dt, eps, max_coeff, relax, st);
         else
-            launch_bwd_wave<bf16e>(H, (const bf16e*)u, (const bf16e*)states, (const bf16e*)gout, alpha_base, channel_scaling,
+            launch_bwd_wave<bf16e>(H, (const bf16e*)u, (const float*)states, (const bf16e*)gout, alpha_base, channel_scaling,
                                    (bf16e*)gu, part, nplanes, C, num_steps, dt, eps, max_coeff, relax, st);
     } else {
         const size_t tb = (size_t)nplanes * H * W * (io_dtype == PDE_IO_BF16 ? 2 : 4);
