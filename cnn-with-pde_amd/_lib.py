@@ -73,9 +73,9 @@ SIGNATURES = {
     "pde_adi_backward_step": (C.c_int, [_D, _i32, _i32, _vp, _vp, _vp, C.POINTER(C.c_uint64), _vp, _vp, _vp, _sz,
                                         _i32, _vp]),
     "pde_adi_param_grads": (C.c_int, [_D, _i32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _vp, _vp]),
-    "pde_adi_mixed_forward": (C.c_int, [_D, _i32, _i32, _vp, _vp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _vp, _sz, _vp]),
+    "pde_adi_mixed_forward": (C.c_int, [_D, _i32, _i32, _vp, _vp, _vp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _vp, _sz, _vp]),
     "pde_adi_mixed_backward_workspace_bytes": (_sz, [_D, _i32, _i32]),
-    "pde_adi_mixed_backward": (C.c_int, [_D, _i32, _i32, _vp, _vp, _vp, _fp, C.POINTER(C.c_uint64), _vp, _fp, _fp, _fp, _fp,
+    "pde_adi_mixed_backward": (C.c_int, [_D, _i32, _i32, _vp, _vp, _vp, _vp, _fp, C.POINTER(C.c_uint64), _vp, _fp, _fp, _fp, _fp,
                                          _fp, _fp, _fp, _fp, _fp, _vp, _vp, _sz, _vp]),
     "pde_adi_small_supported": (C.c_int, [_D, _i32]),
     "pde_adi_mixed_one_launch": (C.c_int, [_D, _i32]),

@@ -455,17 +455,17 @@ struct MixedFn : public torch::autograd::Function<MixedFn> {
             slot = acquire_slot(u.device().index());
             ticket = slot_ticket(slot, d.num_sweeps);
         }
-        // states[k][0]: output of the step's first operator, states[k][1]: of its second (= input of step k + 1)
-        std::vector<int64_t> sh{K, 2};
-        for (auto v : u.sizes()) sh.push_back(v);
-        Tensor states = at::empty(sh, u.options());
-        check(pde_adi_mixed_forward(&d, (int32_t)sps, (int32_t)mode, u.data_ptr(), states.data_ptr(), Mf.data_ptr<float>(),
+        // states[2k]: output of step k's first operator, states[2k+1]: of its second (= input of step k + 1); the last of
+        // them is the layer output and lives in a tensor of its own
+        Tensor states = at::empty(states_shape(2 * K - 1, u), u.options());
+        Tensor y = at::empty_like(u);
+        check(pde_adi_mixed_forward(&d, (int32_t)sps, (int32_t)mode, u.data_ptr(), states.data_ptr(), y.data_ptr(), Mf.data_ptr<float>(),
                                     p[0].data_ptr<float>(), p[1].data_ptr<float>(), p[2].data_ptr<float>(), p[3].data_ptr<float>(),
                                     want_kmax ? kdev.data_ptr<float>() : nullptr, slot ? slot->host : nullptr,
                                     slot ? (void*)slot->ev : nullptr, sws.data_ptr(), (size_t)sws.numel(), (void*)st),
               "pde_adi_mixed_forward");
         if (need_grad) {
-            ctx->save_for_backward({u, states, Mf, p[0], p[1], p[2], p[3]});
+            ctx->save_for_backward({u, states, Mf, p[0], p[1], p[2], p[3], y});
             ctx->saved_data["sws"] = sws;
             if (slot) {
                 ctx->saved_data["ticket"] = ticket;
@@ -479,7 +479,7 @@ struct MixedFn : public torch::autograd::Function<MixedFn> {
             ctx->saved_data["sh2"] = asl.sizes().vec();
             ctx->saved_data["sh3"] = bsl.sizes().vec();
         }
-        return states.select(0, K - 1).select(0, 1).clone();   // never a view of the kept states: callers may write to their result
+        return y;
     }
 
     static variable_list backward(AutogradContext* ctx, variable_list grads) {
@@ -507,7 +507,8 @@ struct MixedFn : public torch::autograd::Function<MixedFn> {
         Tensor gM = at::empty_like(Mf);
         Tensor ws = bytes(pde_adi_mixed_backward_workspace_bytes(&d, sps, popcount2(mask)), u);
         Tensor sws = ctx->saved_data["sws"].toTensor();
-        check(pde_adi_mixed_backward(&d, sps, mode, gy.data_ptr(), u.data_ptr(), states.data_ptr(), Mf.data_ptr<float>(), mask,
+        check(pde_adi_mixed_backward(&d, sps, mode, gy.data_ptr(), u.data_ptr(), states.data_ptr(), saved[7].data_ptr(),
+                                     Mf.data_ptr<float>(), mask,
                                      gu.data_ptr(), saved[3].data_ptr<float>(), saved[4].data_ptr<float>(),
                                      saved[5].data_ptr<float>(), saved[6].data_ptr<float>(), gp[0].data_ptr<float>(),
                                      gp[1].data_ptr<float>(), gp[2].data_ptr<float>(), gp[3].data_ptr<float>(),

@@ -1085,10 +1085,10 @@ static size_t state_bytes(const PdeAdiDesc* d) {
     return (size_t)d->B * d->C * d->N * d->N * (d->io_dtype == PDE_IO_BF16 ? 2 : 4);
 }
 
-static int wide_forward(const PdeAdiDesc* d, int sps, int mode, const void* u, void* states, const float* M,
+static int wide_forward(const PdeAdiDesc* d, int sps, int mode, const void* u, void* states, void* y, const float* M,
                         const void* steps_workspace, int keep, hipStream_t st) {
     WideArgs wa{};
-    wa.u = u; wa.states = states; wa.M = M;
+    wa.u = u; wa.states = states; wa.M = M; wa.last = y;
     wa.coef = reinterpret_cast<const float*>(static_cast<const char*>(steps_workspace) + steps_wide_offset(d, sps));
     wa.B = d->B; wa.K = d->num_sweeps / sps; wa.mode = mode; wa.keep = keep;
     const int grid = d->B < 2048 ? d->B : 2048;
@@ -1104,7 +1104,7 @@ int pde_adi_mixed_one_launch(const PdeAdiDesc* d, int32_t sweeps_per_step) {
     return (check_desc(d) == PDE_OK && wide_supported(d, sweeps_per_step)) ? 1 : 0;
 }
 
-int pde_adi_mixed_forward(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t mode, const void* u, void* states,
+int pde_adi_mixed_forward(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t mode, const void* u, void* states, void* y,
                           const float* M, const float* alpha_base, const float* beta_base, const float* alpha_slope,
                           const float* beta_slope, float* kappa_max, float* kappa_max_host, void* kappa_event,
                           void* steps_workspace, size_t workspace_bytes, void* stream) {
@@ -1117,13 +1117,13 @@ int pde_adi_mixed_forward(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t 
     if (rc != PDE_OK) return rc;
     const int K = d->num_sweeps / sweeps_per_step, HW = d->N * d->N;
     if (wide_supported(d, sweeps_per_step))
-        return wide_forward(d, sweeps_per_step, mode, u, states, M, steps_workspace, 1, static_cast<hipStream_t>(stream));
+        return wide_forward(d, sweeps_per_step, mode, u, states, y, M, steps_workspace, 1, static_cast<hipStream_t>(stream));
     const size_t sb = state_bytes(d);
     char* st = static_cast<char*>(states);
     const void* cur = u;
     for (int k = 0; k < K; ++k) {
         void* a_k = st + (size_t)(2 * k) * sb;
-        void* b_k = st + (size_t)(2 * k + 1) * sb;
+        void* b_k = (k == K - 1 && y) ? y : st + (size_t)(2 * k + 1) * sb;      // the layer output may live outside `states`
         if (mode == 1) {                                   // cifar10.py:91: u <- M u, then the step's sweeps
             rc = pde_channel_mix_forward(d->B, d->C, HW, d->io_dtype, cur, M, a_k, stream);
             if (rc == PDE_OK) rc = pde_adi_forward_step(d, sweeps_per_step, k, a_k, b_k, steps_workspace, stream);
@@ -1145,7 +1145,7 @@ size_t pde_adi_mixed_backward_workspace_bytes(const PdeAdiDesc* d, int32_t sweep
 }
 
 int pde_adi_mixed_backward(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t mode, const void* gy, const void* u,
-                           const void* states, const float* M, const uint64_t ckpt_mask[2], void* gu,
+                           const void* states, const void* y, const float* M, const uint64_t ckpt_mask[2], void* gu,
                            const float* alpha_base, const float* beta_base, const float* alpha_slope,
                            const float* beta_slope, float* g_alpha_base, float* g_beta_base, float* g_alpha_slope,
                            float* g_beta_slope, float* gM, const void* steps_workspace, void* workspace,
@@ -1182,7 +1182,7 @@ int pde_adi_mixed_backward(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t
     for (int k = K - 1; k >= 0; --k) {
         const int first = (k == K - 1), last = (k == 0);
         const void* a_k = st + (size_t)(2 * k) * sb;
-        const void* b_k = st + (size_t)(2 * k + 1) * sb;
+        const void* b_k = (first && y) ? y : st + (size_t)(2 * k + 1) * sb;
         const void* prev = (k == 0) ? u : st + (size_t)(2 * k - 1) * sb;
         void* g_mid = (g_in == buf[0]) ? buf[1] : buf[0];
         void* g_out = last ? gu : ((g_mid == buf[0]) ? buf[1] : buf[0]);

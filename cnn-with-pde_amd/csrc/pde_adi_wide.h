@@ -32,6 +32,7 @@ struct WideArgs {
     const float* coef;      // [S][C][kWideRec]: lane-major records (pde_common.h)
     const float* M;         // [C][C]
     int B, K, mode, keep;   // keep = 0: inference, only the layer output is written
+    void* last;             // nullptr, or where the layer output (slot 2K-1) goes instead
 };
 
 typedef float wide_f32x16 __attribute__((ext_vector_type(16)));
@@ -288,7 +289,8 @@ __global__ __launch_bounds__(64 * WAVES) void adi_wide_fwd_kernel(WideArgs a) {
                 });
             });
             if (a.keep || (mode == 1 && k == K - 1)) {                   // the step's sweep output, for the backward
-                float* dst = st + (size_t)(mode == 1 ? 2 * k + 1 : 2 * k) * tens;
+                const int slot = mode == 1 ? 2 * k + 1 : 2 * k;
+                float* dst = (slot == 2 * K - 1 && a.last != nullptr) ? static_cast<float*>(a.last) : st + (size_t)slot * tens;
                 sfor<0, 4>([&](auto JC) __attribute__((always_inline)) {
                     constexpr int j = decltype(JC)::value;
                     small_store<N, 0, float>(dst, b, C, 4 * w + j, lane, l, hf, T, v[j]);
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(64 * WAVES) void adi_wide_fwd_kernel(WideArgs a) {
             if (mode == 2) wide_mix<WAVES, MM>(v, X, Af, w, lane);       // SVHN.py:71
         }
         if (mode == 2) {
-            float* dst = st + (size_t)(2 * K - 1) * tens;
+            float* dst = a.last != nullptr ? static_cast<float*>(a.last) : st + (size_t)(2 * K - 1) * tens;
             sfor<0, 4>([&](auto JC) __attribute__((always_inline)) {
                 constexpr int j = decltype(JC)::value;
                 small_store<N, 0, float>(dst, b, C, 4 * w + j, lane, l, hf, T, v[j]);

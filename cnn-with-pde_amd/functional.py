@@ -421,11 +421,13 @@ class _AdiMixedFn(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad[:6])
         want_kmax = need_grad and (ckpt == "auto" or kmax_sink is not None)
         kdev = torch.empty(len(sweeps), dtype=torch.float32, device=u.device) if want_kmax else None
-        # states[k][0]: output of the step's first operator, states[k][1]: of its second (= input of step k+1)
-        states = torch.empty((K, 2) + tuple(u.shape), dtype=u.dtype, device=u.device)
+        # states[2k]: output of step k's first operator, states[2k+1]: of its second (= input of step k+1); the last of them
+        # is the layer output and lives in a tensor of its own (no copy, and nobody can reach the kept states through it)
+        states = torch.empty((2 * K - 1,) + tuple(u.shape), dtype=u.dtype, device=u.device)
+        y = torch.empty_like(u)
         with torch.cuda.device(u.device):
             tk = _kmax_channel(len(sweeps)) if want_kmax else None
-            L.check(lib.pde_adi_mixed_forward(C.byref(d), sps, 1 if mode == "pre" else 2, _ptr(u), _ptr(states), _ptr(Mf),
+            L.check(lib.pde_adi_mixed_forward(C.byref(d), sps, 1 if mode == "pre" else 2, _ptr(u), _ptr(states), _ptr(y), _ptr(Mf),
                                               *[_ptr(t) for t in p], _ptr(kdev), _ptr(tk.host if tk else None),
                                               C.c_void_p(tk.event.cuda_event if tk else 0),
                                               _ptr(sws), sws.numel(), _stream()),
@@ -433,19 +435,18 @@ class _AdiMixedFn(torch.autograd.Function):
             ctx.kmax = tk
             if want_kmax and kmax_sink is not None:
                 kmax_sink.append(tk)
-        y = states[K - 1, 1]
         if need_grad:
-            ctx.save_for_backward(u, states, Mf, *p)
+            ctx.save_for_backward(u, states, y, Mf, *p)
             ctx.sws = sws
         ctx.cfg = (steps, mode, smooth3, clamp_max, eps, ckpt)
         ctx.param_shapes = [t.shape for t in (ab, bb, asl, bsl)]
         ctx.M_dtype = M.dtype
-        return y.clone()        # never a view of the saved states: callers may modify their result in place
+        return y
 
     @staticmethod
     def backward(ctx, gy):
         lib = L.load()
-        u, states, Mf, *p = ctx.saved_tensors
+        u, states, y, Mf, *p = ctx.saved_tensors
         steps, mode, smooth3, clamp_max, eps, ckpt = ctx.cfg
         B, Cc, N, _ = u.shape
         sps, K, HW = len(steps[0]), len(steps), N * N
@@ -467,7 +468,7 @@ class _AdiMixedFn(torch.autograd.Function):
         gM = torch.empty_like(Mf)
         with torch.cuda.device(u.device):
             L.check(lib.pde_adi_mixed_backward(C.byref(d), sps, 1 if mode == "pre" else 2, _ptr(g_in), _ptr(u), _ptr(states),
-                                               _ptr(Mf), mask, _ptr(g_a), *[_ptr(t) for t in p], *[_ptr(t) for t in gp],
+                                               _ptr(y), _ptr(Mf), mask, _ptr(g_a), *[_ptr(t) for t in p], *[_ptr(t) for t in gp],
                                                _ptr(gM), _ptr(ctx.sws), _ptr(ws), ws.numel(), _stream()),
                     "pde_adi_mixed_backward")
         gp = [g.reshape(s) for g, s in zip(gp, ctx.param_shapes)]

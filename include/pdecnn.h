@@ -178,14 +178,18 @@ int pde_adi_param_grads(const PdeAdiDesc* d, int32_t sweeps_per_step,
  * recomputes the other slots itself when its checkpoints need them, so the contract above is unchanged. */
 int pde_adi_mixed_one_launch(const PdeAdiDesc* d, int32_t sweeps_per_step);
 int pde_adi_mixed_forward(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t mode,
-                          const void* u, void* states, const float* M,
+                          const void* u, void* states,
+                          void* y /* NULL, or where the layer output goes INSTEAD of states[2K-1] (`states` then needs 2K-1
+                                     tensors only; hand the same `y` to pde_adi_mixed_backward) */,
+                          const float* M,
                           const float* alpha_base, const float* beta_base,
                           const float* alpha_slope, const float* beta_slope,
                           float* kappa_max, float* kappa_max_host, void* kappa_event /* as in pde_adi_forward */,
                           void* steps_workspace, size_t workspace_bytes, void* stream);
 size_t pde_adi_mixed_backward_workspace_bytes(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t num_checkpoints);
 int pde_adi_mixed_backward(const PdeAdiDesc* d, int32_t sweeps_per_step, int32_t mode,
-                           const void* gy, const void* u, const void* states, const float* M,
+                           const void* gy, const void* u, const void* states, const void* y /* as in the forward */,
+                           const float* M,
                            const uint64_t ckpt_mask[2], void* gu,
                            const float* alpha_base, const float* beta_base,
                            const float* alpha_slope, const float* beta_slope,
