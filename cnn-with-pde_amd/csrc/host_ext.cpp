@@ -82,8 +82,10 @@ struct Ring {
 };
 
 Ring* ring_of(int dev) {
-    static std::mutex mu;
-    static std::vector<std::unique_ptr<Ring>> rings;
+    // (never destroyed: a slot's ticket may be released — its deleter run — while the process is exiting, after static
+    //  destructors of this library would have run)
+    static std::mutex& mu = *new std::mutex();
+    static std::vector<std::unique_ptr<Ring>>& rings = *new std::vector<std::unique_ptr<Ring>>();
     std::lock_guard<std::mutex> g(mu);
     if ((int)rings.size() <= dev) rings.resize(dev + 1);
     if (!rings[dev]) {
@@ -744,8 +746,9 @@ variable_list multi(const Tensor& u, const std::optional<Tensor>& weights, std::
 Tensor sym_workspace(int64_t B, int64_t D, const Tensor& like, hipStream_t st) {
     const size_t n = pde_sym_layer_workspace_bytes((int32_t)B, (int32_t)D);
     if (n == 0) return Tensor();
-    static std::mutex mu;
-    static std::map<std::tuple<int, void*, int64_t, size_t>, Tensor> cache;
+    // (never destroyed: device tensors must not be freed from a static destructor, after the allocator may be gone)
+    static std::mutex& mu = *new std::mutex();
+    static std::map<std::tuple<int, void*, int64_t, size_t>, Tensor>& cache = *new std::map<std::tuple<int, void*, int64_t, size_t>, Tensor>();
     std::lock_guard<std::mutex> g(mu);
     auto key = std::make_tuple((int)like.device().index(), (void*)st, D, n);
     auto it = cache.find(key);
