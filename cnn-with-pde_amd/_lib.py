@@ -102,7 +102,6 @@ SIGNATURES = {
     "pde_skip_blend_forward": (C.c_int, [C.c_int64, _i32, _vp, _vp, _fp, _vp, _vp]),
     "pde_skip_blend_backward_workspace_bytes": (_sz, [C.c_int64]),
     "pde_skip_blend_backward": (C.c_int, [C.c_int64, _i32, _vp, _vp, _vp, _fp, _vp, _vp, _fp, _vp, _sz, _vp]),
-    "pde_explicit5_states_fp32": (C.c_int, [_i32, _i32]),
     "pde_explicit5_forward": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _vp, _fp, _fp, _f32, _f32, _f32, _f32, _i32, _vp,
                                         _vp, _vp]),
     "pde_explicit5_backward_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32, _i32]),

@@ -76,29 +76,31 @@ __device__ __forceinline__ float4 lap0_4(const IO* plane, int H, int W, int h, i
     return o;
 }
 
-template <typename IO>
-__global__ __launch_bounds__(256) void explicit5_fwd_kernel(const IO* __restrict__ u, const float* __restrict__ alpha,
-                                                            const float* __restrict__ scale, IO* __restrict__ out,
+// (TI / TO: the step's input and output types — a call with bf16 tensors reads bf16 in its first step and writes bf16 in
+//  its last; what passes between the steps is fp32)
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void explicit5_fwd_kernel(const TI* __restrict__ u, const float* __restrict__ alpha,
+                                                            const float* __restrict__ scale, TO* __restrict__ out,
                                                             int C, int H, int W, float dt, float eps, float maxc,
                                                             float relax) {
     const int pc = blockIdx.x;                         // plane index b*C + c
     const int c = pc % C;
     const float a = fminf(fmaxf(alpha[c], eps), maxc) * dt;
     const float s = scale[c];
-    const IO* plane = u + (size_t)pc * H * W;
-    IO* oplane = out + (size_t)pc * H * W;
+    const TI* plane = u + (size_t)pc * H * W;
+    TO* oplane = out + (size_t)pc * H * W;
     const int W4 = W / 4;
     for (int f = threadIdx.x; f < H * W4; f += 256) {
         const int h = f / W4, w0 = 4 * (f % W4);
-        const float4 cu = V4<IO>::ld(plane + (size_t)h * W + w0);
-        const float4 lp = lap0_4<IO>(plane, H, W, h, w0, cu);          // Lap0(u); Lap0(v) = s*Lap0(u)
+        const float4 cu = V4<TI>::ld(plane + (size_t)h * W + w0);
+        const float4 lp = lap0_4<TI>(plane, H, W, h, w0, cu);          // Lap0(u); Lap0(v) = s*Lap0(u)
         float4 o;
         // v = s u; new = v + a*(s*lap); out = u + relax*(new - u)
         { const float v = s * cu.x; const float nw = v + a * (s * lp.x); o.x = cu.x + relax * (nw - cu.x); }
         { const float v = s * cu.y; const float nw = v + a * (s * lp.y); o.y = cu.y + relax * (nw - cu.y); }
         { const float v = s * cu.z; const float nw = v + a * (s * lp.z); o.z = cu.z + relax * (nw - cu.z); }
         { const float v = s * cu.w; const float nw = v + a * (s * lp.w); o.w = cu.w + relax * (nw - cu.w); }
-        V4<IO>::st(oplane + (size_t)h * W + w0, o);
+        V4<TO>::st(oplane + (size_t)h * W + w0, o);
     }
 }
 
@@ -111,10 +113,10 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh) {
     return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
-template <typename IO>
-__global__ __launch_bounds__(256) void explicit5_bwd_kernel(const IO* __restrict__ u, const IO* __restrict__ g,
+template <typename TU, typename TG, typename TO>
+__global__ __launch_bounds__(256) void explicit5_bwd_kernel(const TU* __restrict__ u, const TG* __restrict__ g,
                                                             const float* __restrict__ alpha,
-                                                            const float* __restrict__ scale, IO* __restrict__ gu,
+                                                            const float* __restrict__ scale, TO* __restrict__ gu,
                                                             float* __restrict__ part, int C, int H, int W, float dt,
                                                             float eps, float maxc, float relax, int accumulate) {
     __shared__ float sh[4];
@@ -122,22 +124,22 @@ __global__ __launch_bounds__(256) void explicit5_bwd_kernel(const IO* __restrict
     const int c = pc % C;
     const float a = fminf(fmaxf(alpha[c], eps), maxc) * dt;
     const float s = scale[c];
-    const IO* up = u + (size_t)pc * H * W;
-    const IO* gp = g + (size_t)pc * H * W;
-    IO* op = gu + (size_t)pc * H * W;
+    const TU* up = u + (size_t)pc * H * W;
+    const TG* gp = g + (size_t)pc * H * W;
+    TO* op = gu + (size_t)pc * H * W;
     const int W4 = W / 4;
     float p1 = 0.f, p2 = 0.f;                          // sum g*u, sum Lap0(g)*u
     for (int f = threadIdx.x; f < H * W4; f += 256) {
         const int h = f / W4, w0 = 4 * (f % W4);
-        const float4 cg = V4<IO>::ld(gp + (size_t)h * W + w0);
-        const float4 cu = V4<IO>::ld_once(up + (size_t)h * W + w0);
-        const float4 lg = lap0_4<IO>(gp, H, W, h, w0, cg);
+        const float4 cg = V4<TG>::ld(gp + (size_t)h * W + w0);
+        const float4 cu = V4<TU>::ld_once(up + (size_t)h * W + w0);
+        const float4 lg = lap0_4<TG>(gp, H, W, h, w0, cg);
         float4 o;
         o.x = (1.f - relax) * cg.x + relax * s * (cg.x + a * lg.x);
         o.y = (1.f - relax) * cg.y + relax * s * (cg.y + a * lg.y);
         o.z = (1.f - relax) * cg.z + relax * s * (cg.z + a * lg.z);
         o.w = (1.f - relax) * cg.w + relax * s * (cg.w + a * lg.w);
-        V4<IO>::st(op + (size_t)h * W + w0, o);
+        V4<TO>::st(op + (size_t)h * W + w0, o);
         p1 += cg.x * cu.x + cg.y * cu.y + cg.z * cu.z + cg.w * cu.w;
         p2 += lg.x * cu.x + lg.y * cu.y + lg.z * cu.z + lg.w * cu.w;
     }
@@ -513,29 +515,32 @@ int pde_explicit5_forward(int32_t B, int32_t C, int32_t H, int32_t W, int32_t io
                                    num_steps, dt, eps, max_coeff, relax, st);
         return check_launch();
     }
-    if (num_steps > 1 && !states) return PDE_E_BADARG;     // generic sizes: one launch per step through `states`
-    const size_t tb = (size_t)nplanes * H * W * (io_dtype == PDE_IO_BF16 ? 2 : 4);
+    if (num_steps > 1 && !states) return PDE_E_BADARG;     // generic sizes: one launch per step through `states` (fp32)
+    const size_t tf = (size_t)nplanes * H * W;
+    float* sf = static_cast<float*>(states);
+    const bool bf = io_dtype == PDE_IO_BF16;
+#define PDE_EX_FWD(TI, TO, SRC, DST)                                                                                       \
+    hipLaunchKernelGGL((explicit5_fwd_kernel<TI, TO>), dim3(nplanes), dim3(256), 0, st, (const TI*)(SRC), alpha_base,        \
+                       channel_scaling, (TO*)(DST), C, H, W, dt, eps, max_coeff, relax)
     for (int k = 0; k < num_steps; ++k) {
-        const void* src = (k == 0) ? u : static_cast<const char*>(states) + (size_t)(k - 1) * tb;
-        void* dst = (k == num_steps - 1) ? out : static_cast<char*>(states) + (size_t)k * tb;
-        if (io_dtype == PDE_IO_F32)
-            hipLaunchKernelGGL((explicit5_fwd_kernel<float>), dim3(nplanes), dim3(256), 0, st, (const float*)src, alpha_base,
-                               channel_scaling, (float*)dst, C, H, W, dt, eps, max_coeff, relax);
-        else
-            hipLaunchKernelGGL((explicit5_fwd_kernel<bf16e>), dim3(nplanes), dim3(256), 0, st, (const bf16e*)src, alpha_base,
-                               channel_scaling, (bf16e*)dst, C, H, W, dt, eps, max_coeff, relax);
+        const bool first = k == 0, last = k == num_steps - 1;
+        const void* src = first ? u : static_cast<const void*>(sf + (size_t)(k - 1) * tf);
+        void* dst = last ? out : static_cast<void*>(sf + (size_t)k * tf);
+        if (!bf || (!first && !last)) PDE_EX_FWD(float, float, src, dst);
+        else if (first && last) PDE_EX_FWD(bf16e, bf16e, src, dst);
+        else if (first) PDE_EX_FWD(bf16e, float, src, dst);
+        else PDE_EX_FWD(float, bf16e, src, dst);
     }
+#undef PDE_EX_FWD
     return check_launch();
 }
-
-int pde_explicit5_states_fp32(int32_t H, int32_t W) { return wave_plane_ok(H, W) ? 1 : 0; }
 
 size_t pde_explicit5_backward_workspace_bytes(int32_t B, int32_t C, int32_t H, int32_t W, int32_t io_dtype,
                                               int32_t num_steps) {
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || num_steps < 1) return 0;
     size_t b = align256((size_t)B * C * 2 * sizeof(float));
     if (num_steps > 1 && !wave_plane_ok(H, W))             // generic sizes: two gradient buffers to ping-pong through
-        b += 2 * align256((size_t)B * C * H * W * (io_dtype == PDE_IO_BF16 ? 2 : 4));
+        b += 2 * align256((size_t)B * C * H * W * sizeof(float));
     return b;
 }
 
@@ -560,23 +565,29 @@ int pde_explicit5_backward(int32_t B, int32_t C, int32_t H, int32_t W, int32_t i
             launch_bwd_wave<bf16e>(H, (const bf16e*)u, (const float*)states, (const bf16e*)gout, alpha_base, channel_scaling,
                                    (bf16e*)gu, part, nplanes, C, num_steps, dt, eps, max_coeff, relax, st);
     } else {
-        const size_t tb = (size_t)nplanes * H * W * (io_dtype == PDE_IO_BF16 ? 2 : 4);
-        char* buf0 = static_cast<char*>(workspace) + align256((size_t)nplanes * 2 * sizeof(float));
-        char* buf1 = buf0 + align256(tb);
+        // what passes between the steps is fp32 (the states the forward left, the gradient buffers here), whatever io_dtype
+        const size_t tf = (size_t)nplanes * H * W;
+        float* buf0 = reinterpret_cast<float*>(static_cast<char*>(workspace) + align256((size_t)nplanes * 2 * sizeof(float)));
+        float* buf1 = reinterpret_cast<float*>(reinterpret_cast<char*>(buf0) + align256(tf * sizeof(float)));
+        const float* sf = static_cast<const float*>(states);
+        const bool bf = io_dtype == PDE_IO_BF16;
         const void* gin = gout;
+#define PDE_EX_BWD(TU, TG, TO, UP, GIN, GDST, ACC)                                                                          \
+    hipLaunchKernelGGL((explicit5_bwd_kernel<TU, TG, TO>), dim3(nplanes), dim3(256), 0, st, (const TU*)(UP), (const TG*)(GIN), \
+                       alpha_base, channel_scaling, (TO*)(GDST), part, C, H, W, dt, eps, max_coeff, relax, ACC)
         for (int k = num_steps; k >= 1; --k) {
-            const void* up = (k == 1) ? u : static_cast<const char*>(states) + (size_t)(k - 2) * tb;
-            void* gdst = (k == 1) ? gu : (gin == buf0 ? buf1 : buf0);
-            if (io_dtype == PDE_IO_F32)
-                hipLaunchKernelGGL((explicit5_bwd_kernel<float>), dim3(nplanes), dim3(256), 0, st, (const float*)up,
-                                   (const float*)gin, alpha_base, channel_scaling, (float*)gdst, part, C, H, W, dt, eps,
-                                   max_coeff, relax, k == num_steps ? 0 : 1);
-            else
-                hipLaunchKernelGGL((explicit5_bwd_kernel<bf16e>), dim3(nplanes), dim3(256), 0, st, (const bf16e*)up,
-                                   (const bf16e*)gin, alpha_base, channel_scaling, (bf16e*)gdst, part, C, H, W, dt, eps,
-                                   max_coeff, relax, k == num_steps ? 0 : 1);
+            const bool ufirst = k == 1, gfirst = k == num_steps;       // u / gu are the caller's tensors, gout too
+            const void* up = ufirst ? u : static_cast<const void*>(sf + (size_t)(k - 2) * tf);
+            void* gdst = ufirst ? gu : static_cast<void*>(gin == buf0 ? buf1 : buf0);
+            const int acc = gfirst ? 0 : 1;
+            if (!bf) PDE_EX_BWD(float, float, float, up, gin, gdst, acc);
+            else if (ufirst && gfirst) PDE_EX_BWD(bf16e, bf16e, bf16e, up, gin, gdst, acc);
+            else if (ufirst) PDE_EX_BWD(bf16e, float, bf16e, up, gin, gdst, acc);
+            else if (gfirst) PDE_EX_BWD(float, bf16e, float, up, gin, gdst, acc);
+            else PDE_EX_BWD(float, float, float, up, gin, gdst, acc);
             gin = gdst;
         }
+#undef PDE_EX_BWD
     }
     hipLaunchKernelGGL(explicit5_pgrad_kernel, dim3(C), dim3(256), 0, st, part, alpha_base, channel_scaling,
                        g_alpha_base, g_channel_scaling, B, C, dt, eps, max_coeff, relax);

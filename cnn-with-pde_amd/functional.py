@@ -1159,10 +1159,10 @@ class _Explicit5Fn(torch.autograd.Function):
         s = channel_scaling.detach().to(torch.float32).contiguous()
         out = torch.empty_like(u)
         need_grad = any(ctx.needs_input_grad[:3])
-        fused = bool(lib.pde_explicit5_states_fp32(H, W))        # planes that stay in registers over all steps
-        # inputs of steps 2..num_steps: what the backward reads (and what chains the steps for generic plane sizes); the
-        # fused planes keep them in fp32 whatever the tensors' type
-        states = torch.empty((num_steps - 1,) + tuple(u.shape), dtype=torch.float32 if fused else u.dtype, device=u.device) \
+        fused = (H, W) in ((64, 64), (32, 32), (16, 16))         # planes that stay in registers over all steps
+        # inputs of steps 2..num_steps: what the backward reads (and what chains the steps for generic plane sizes): fp32
+        # whatever the tensors' type
+        states = torch.empty((num_steps - 1,) + tuple(u.shape), dtype=torch.float32, device=u.device) \
             if num_steps > 1 and (need_grad or not fused) else None
         with torch.cuda.device(u.device):
             L.check(lib.pde_explicit5_forward(B, Cc, H, W, _io_dtype(u), _ptr(u), _ptr(a), _ptr(s), dt, eps, max_coeff,

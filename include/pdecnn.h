@@ -338,11 +338,10 @@ int pde_bn_pool_backward(int32_t B, int32_t C, int32_t N, const float* x, const 
 /* tiny_imagenet.py:34-72: `num_steps` relaxed explicit steps (the reference's loop :44-49), each
  *   a_c = clamp(alpha_base_c, eps, max_coeff);  v = s_c u;
  *   u <- u + relax*(v + a_c*dt*Lap0(v) - u)      (Lap0: zero ghost cells, padding=1)
- * u,out: (B,C,H,W) of io_dtype.  states: NULL, or room for (num_steps-1) tensors of u's shape that receive the
- * inputs of steps 2..num_steps (what pde_explicit5_backward needs) — of u's type, except for planes of 64x64, 32x32
- * or 16x16, whose time loop stays in registers (one launch) and whose states are ALWAYS fp32 (pde_explicit5_states_fp32
- * says which); required for num_steps > 1 unless the plane is one of those. */
-int pde_explicit5_states_fp32(int32_t H, int32_t W);
+ * u,out: (B,C,H,W) of io_dtype.  states: NULL, or room for (num_steps-1) FP32 tensors of u's shape (whatever io_dtype:
+ * with bf16 tensors only the layer's own input, output and gradients are bf16) that receive the inputs of steps
+ * 2..num_steps (what pde_explicit5_backward needs); required for num_steps > 1 unless the plane is 64x64, 32x32 or 16x16
+ * (those stay in registers over all steps, one launch). */
 int pde_explicit5_forward(int32_t B, int32_t C, int32_t H, int32_t W, int32_t io_dtype,
                           const void* u, const float* alpha_base, const float* channel_scaling,
                           float dt, float eps, float max_coeff, float relax,
