@@ -189,10 +189,12 @@ Tensor bytes(size_t n, const Tensor& like) {
 }
 
 struct AdiFn : public torch::autograd::Function<AdiFn> {
-    // ckpt_mode: 0 = explicit mask (ckpt_lo/hi), 1 = "auto" (planned in the backward from this call's coefficients)
+    // ckpt_mode: 0 = explicit mask (ckpt_lo/hi), 1 = "auto" (planned in the backward from this call's coefficients),
+    // 2 = explicit mask, and this call's coefficient maxima go to a slot the CALLER owns (slot_out: where to leave it) —
+    // the "lagged" policy of layers.py: the next call plans from them, nobody waits
     static Tensor forward(AutogradContext* ctx, const Tensor& u_in, const Tensor& ab, const Tensor& bb, const Tensor& asl,
                           const Tensor& bsl, int64_t desc_addr, int64_t ckpt_mode, int64_t ckpt_lo, int64_t ckpt_hi,
-                          double amax, bool need_grad) {
+                          double amax, bool need_grad, int64_t slot_out) {
         PDE_REQUIRE(u_in.is_cuda() && ab.is_cuda() && bb.is_cuda() && asl.is_cuda() && bsl.is_cuda(),
                     "libpdecnn_hip operators need CUDA/HIP tensors (there is no CPU fallback)");
         PDE_REQUIRE(u_in.dim() == 4 && u_in.size(2) == u_in.size(3), "expected (B,C,N,N), got ", u_in.sizes());
@@ -205,7 +207,7 @@ struct AdiFn : public torch::autograd::Function<AdiFn> {
         PDE_REQUIRE(d.B == B && d.C == C && d.N == N && d.io_dtype == (u.scalar_type() == at::kBFloat16 ? PDE_IO_BF16 : PDE_IO_F32),
                     "descriptor does not match the tensor");
         Tensor p[4] = {as_chw(ab, C, N), as_chw(bb, C, N), as_chw(asl, C, N), as_chw(bsl, C, N)};
-        const bool want_kmax = need_grad && ckpt_mode == 1;
+        const bool want_kmax = need_grad && (ckpt_mode == 1 || ckpt_mode == 2);
         c10::hip::HIPGuardMasqueradingAsCUDA guard(u.device());
         hipStream_t st = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(u.device().index()).stream();
         Tensor y = at::empty_like(u);
@@ -215,7 +217,8 @@ struct AdiFn : public torch::autograd::Function<AdiFn> {
         if (want_kmax) {
             kdev = at::empty({(int64_t)d.num_sweeps}, u.options().dtype(at::kFloat));
             slot = acquire_slot(u.device().index());
-            ticket = slot_ticket(slot, d.num_sweeps);
+            if (ckpt_mode == 1) ticket = slot_ticket(slot, d.num_sweeps);
+            else *reinterpret_cast<Slot**>(slot_out) = slot;           // the caller's ticket holds it
         }
         check(pde_adi_forward(&d, u.data_ptr(), y.data_ptr(), p[0].data_ptr<float>(), p[1].data_ptr<float>(),
                               p[2].data_ptr<float>(), p[3].data_ptr<float>(), want_kmax ? kdev.data_ptr<float>() : nullptr,
@@ -226,10 +229,11 @@ struct AdiFn : public torch::autograd::Function<AdiFn> {
             const bool explicit_none = ckpt_mode == 0 && ckpt_lo == 0 && ckpt_hi == 0;
             ctx->save_for_backward({y, explicit_none ? Tensor() : u, p[0], p[1], p[2], p[3]});
             ctx->saved_data["ws"] = ws;                      // the factorisation, reused by the backward
-            if (slot) {
+            if (slot && ckpt_mode == 1) {
                 ctx->saved_data["ticket"] = ticket;
                 ctx->saved_data["slot"] = (int64_t) reinterpret_cast<intptr_t>(slot);
             }
+            if (kdev.defined()) ctx->saved_data["kdev"] = kdev;       // (the device copy lives as long as the node)
             ctx->saved_data["desc"] = std::string(reinterpret_cast<const char*>(&d), sizeof(d));
             ctx->saved_data["ckpt"] = std::vector<int64_t>{ckpt_mode, ckpt_lo, ckpt_hi};
             ctx->saved_data["amax"] = amax;
@@ -272,7 +276,7 @@ struct AdiFn : public torch::autograd::Function<AdiFn> {
                                gp[2].data_ptr<float>(), gp[3].data_ptr<float>(), fws.data_ptr(), ws.data_ptr(),
                                (size_t)ws.numel(), (void*)st),
               "pde_adi_backward");
-        return {gu, gp[0], gp[1], gp[2], gp[3], Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+        return {gu, gp[0], gp[1], gp[2], gp[3], Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
     }
 };
 
@@ -281,7 +285,32 @@ Tensor adi(const Tensor& u, const Tensor& ab, const Tensor& bb, const Tensor& as
     // forward() runs with grad mode off: whether anything is kept for a backward is decided out here
     const bool need_grad = at::GradMode::is_enabled() && (u.requires_grad() || ab.requires_grad() || bb.requires_grad() ||
                                                           asl.requires_grad() || bsl.requires_grad());
-    return AdiFn::apply(u, ab, bb, asl, bsl, desc_addr, ckpt_mode, ckpt_lo, ckpt_hi, amax, need_grad);
+    return AdiFn::apply(u, ab, bb, asl, bsl, desc_addr, ckpt_mode, ckpt_lo, ckpt_hi, amax, need_grad, (int64_t)0);
+}
+
+// The coefficient maxima of one call, for whoever plans a LATER call from them (layers.py, "lagged" policy): `event`
+// / `query()` / `host` as the ctypes path's tickets have them.  Holds its pinned slot until it is dropped.
+struct Ticket {
+    Slot* slot;
+    int n;
+    Ticket(Slot* s, int n_) : slot(s), n(n_) {}
+    Ticket(const Ticket&) = delete;
+    ~Ticket() { release_slot(slot); }
+    bool query() const { return hipEventQuery(slot->ev) == hipSuccess; }
+    void synchronize() const { wait_event(slot->ev); }
+    Tensor host() const { return at::from_blob(slot->host, {n}, at::TensorOptions().dtype(at::kFloat)).clone(); }
+};
+
+std::pair<Tensor, std::shared_ptr<Ticket>> adi_lagged(const Tensor& u, const Tensor& ab, const Tensor& bb, const Tensor& asl,
+                                                      const Tensor& bsl, int64_t desc_addr, int64_t ckpt_lo, int64_t ckpt_hi) {
+    const bool need_grad = at::GradMode::is_enabled() && (u.requires_grad() || ab.requires_grad() || bb.requires_grad() ||
+                                                          asl.requires_grad() || bsl.requires_grad());
+    Slot* slot = nullptr;
+    Tensor y = AdiFn::apply(u, ab, bb, asl, bsl, desc_addr, (int64_t)2, ckpt_lo, ckpt_hi, 0.0, need_grad,
+                            (int64_t) reinterpret_cast<intptr_t>(&slot));
+    PdeAdiDesc d;
+    std::memcpy(&d, reinterpret_cast<const void*>(desc_addr), sizeof(d));
+    return {y, slot ? std::make_shared<Ticket>(slot, d.num_sweeps) : std::shared_ptr<Ticket>()};
 }
 
 
@@ -831,6 +860,19 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("adi", &adi, "functional.adi_diffuse without the interpreter: one implicit diffusion layer call",
           py::arg("u"), py::arg("alpha_base"), py::arg("beta_base"), py::arg("alpha_time_coeff"), py::arg("beta_time_coeff"),
           py::arg("desc_addr"), py::arg("ckpt_mode"), py::arg("ckpt_lo"), py::arg("ckpt_hi"), py::arg("amax"));
+    py::class_<Ticket, std::shared_ptr<Ticket>>(m, "Ticket", "the per-sweep coefficient maxima of one call (pinned slot + event)")
+        .def("query", &Ticket::query)
+        .def("synchronize", &Ticket::synchronize)
+        .def("wait", [](std::shared_ptr<Ticket> t) {
+            t->synchronize();
+            std::vector<float> v(t->slot->host, t->slot->host + t->n);
+            return v;
+        })
+        .def_property_readonly("host", &Ticket::host)
+        .def_property_readonly("event", [](std::shared_ptr<Ticket> t) { return t; });
+    m.def("adi_lagged", &adi_lagged, "adi with an explicit checkpoint mask that also delivers this call's coefficient maxima",
+          py::arg("u"), py::arg("alpha_base"), py::arg("beta_base"), py::arg("alpha_time_coeff"), py::arg("beta_time_coeff"),
+          py::arg("desc_addr"), py::arg("ckpt_lo"), py::arg("ckpt_hi"));
     m.def("small", &small, "functional.adi_diffuse_small: one layer with a channel operator, C <= 4, one launch per pass",
           py::arg("u"), py::arg("alpha_base"), py::arg("beta_base"), py::arg("alpha_time_coeff"), py::arg("beta_time_coeff"),
           py::arg("M"), py::arg("skip_weight"), py::arg("desc_addr"), py::arg("sweeps_per_step"), py::arg("mode"),

@@ -839,7 +839,8 @@ def adi_diffuse(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff, swe
         return _empty_passthrough(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff)
     if not isinstance(sweeps, tuple):
         sweeps = tuple(sweeps)
-    if kmax_sink is None and (checkpoints == "auto" or isinstance(checkpoints, int)):
+    if (kmax_sink is None and (checkpoints == "auto" or isinstance(checkpoints, int))) or \
+            (kmax_sink is not None and isinstance(checkpoints, int)):
         H = L.host_ext()
         if H is not None and u.dim() == 4 and u.is_cuda and u.dtype in (torch.float32, torch.bfloat16, torch.float16,
                                                                         torch.float64):
@@ -853,6 +854,11 @@ def adi_diffuse(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff, swe
                 bits = int(checkpoints)
                 mode, lo, hi = 0, bits & _M64, (bits >> 64) & _M64
                 lo, hi = (lo - (1 << 64) if lo >> 63 else lo), (hi - (1 << 64) if hi >> 63 else hi)
+            if kmax_sink is not None:                         # "lagged": an explicit mask now, the maxima for the next plan
+                y, tk = H.adi_lagged(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff, C.addressof(d), lo, hi)
+                if tk is not None:
+                    kmax_sink.append(tk)
+                return y
             return H.adi(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff, C.addressof(d), mode, lo, hi, CKPT_AMAX)
     return _AdiFn.apply(u, alpha_base, beta_base, alpha_time_coeff, beta_time_coeff,
                         sweeps, bool(smooth3), clamp_max, float(eps), checkpoints, kmax_sink)
