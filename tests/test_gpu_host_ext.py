@@ -247,3 +247,43 @@ def test_per_step_layers_match_bitwise(which, C_, ck, dtype):
         torch.cuda.synchronize()
         return [y.detach().clone()] + _grads_of([l], [xx])
     _both_paths(fn)
+
+
+@pytest.mark.gpu
+def test_lagged_policy_through_the_native_path():
+    """layers.py "lagged": an explicit mask now, this call's coefficient maxima for the next plan.  The native node hands
+    them over in a ticket with the ctypes tickets' interface (event.query(), host); three calls (cold cache, warm cache,
+    after a parameter change) give bitwise what the ctypes path gives, and the plan follows the coefficients."""
+    from cnn_with_pde_amd import _lib as L
+    ext = L.host_ext()
+    assert ext is not None
+    outs = {}
+    for native in (True, False):
+        L._host = ext if native else False
+        try:
+            l, shape, g = _layer("fashion")                   # large coefficients: the plans have checkpoints
+            l.checkpoint_policy = "lagged"
+            x = torch.randn(*shape, generator=g).cuda()
+            gy = torch.randn(*shape, generator=g).cuda()
+            res = []
+            for it in range(3):
+                if it == 2:
+                    with torch.no_grad():
+                        l.alpha_base.mul_(0.01)               # tiny coefficients: the next plan needs no checkpoint
+                for p in l.parameters():
+                    p.grad = None
+                xx = x.clone().requires_grad_(True)
+                y = l(xx)
+                assert (type(y.grad_fn).__name__ == "CppFunction") == native
+                y.backward(gy)
+                torch.cuda.synchronize()
+                res += [y.detach().clone(), xx.grad.clone()] + [p.grad.clone() for p in l.parameters()]
+            cache = l.__dict__["_kmax_cache"]
+            tk, mask = next(iter(cache.values()))
+            assert tk.event.query() and len(tk.host.tolist()) == len(l._schedule().flat)
+            res.append(torch.tensor(float(mask)))
+            outs[native] = res
+        finally:
+            L._host = ext
+    for i, (s, t) in enumerate(zip(outs[True], outs[False])):
+        assert torch.equal(s, t), i
