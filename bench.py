@@ -80,7 +80,34 @@ def run_steps(layer, u, gy, n, dist_on, flat, spans=None):
                 flat.finish()
 
 
-PRECONDITION_STEPS = 150   # untimed steps of the headline workload run as part of set-up (see main)
+PRECONDITION_BATCH = 50    # set-up (see main): untimed batches of this many steps of the headline workload ...
+PRECONDITION_MAX_S = 6.0   # ... until the batch time has stopped falling, or this many seconds
+
+
+def precondition(layer, u, gy, dist_on, flat):
+    """Untimed set-up: run the workload until its step time has stopped falling (three batches in a row within 1 % of the
+    best seen), at most PRECONDITION_MAX_S seconds.  Every rank takes the same decision (the batch times are max-reduced)."""
+    import torch.distributed as dist
+    best, steady, hist = None, 0, []
+    t_start = time.perf_counter()
+    while True:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(layer, u, gy, PRECONDITION_BATCH, dist_on, flat)
+        torch.cuda.synchronize()
+        bt = (time.perf_counter() - t0) / PRECONDITION_BATCH * 1e3
+        elapsed = time.perf_counter() - t_start
+        if dist_on:
+            t = torch.tensor([bt, elapsed], device=u.device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            bt, elapsed = float(t[0]), float(t[1])
+        hist.append(bt)
+        steady = steady + 1 if (best is not None and bt <= best * 1.01) else 0
+        best = bt if best is None else min(best, bt)
+        if (steady >= 3 and len(hist) >= 4) or elapsed > PRECONDITION_MAX_S:
+            break
+    return {"steps": len(hist) * PRECONDITION_BATCH, "seconds": round(elapsed, 2),
+            "ms_per_step_first_batch": round(hist[0], 4), "ms_per_step_last_batch": round(hist[-1], 4)}
 LAST_DIAG = {}        # per-rank figures of the latest timed() call on a multi-rank run (rank 0 puts them in the JSON line)
 
 
@@ -456,10 +483,10 @@ def main():
     # boxes: +0.1 ms per step) shows in the step time.  The same loop under "auto" is timed beside it (`eager_auto_policy`).
     layer.checkpoint_policy = "lagged"
     # Set-up, before the W warm-up steps and the K timed ones: the device and the allocator in their steady state.  A
-    # chip that has just been idle needs tens of milliseconds of this load before it holds its clocks (with 5 warm-up
-    # steps the first timed leg read 0.499 ms per step on a box whose steady state is 0.456), and torch's caching
-    # allocator takes its 134 MB blocks from the driver during the first steps.
-    run_steps(layer, u, gy, PRECONDITION_STEPS, dist_on, flat)
+    # chip that has been idle needs this load for a while before it holds its clocks (with 5 warm-up steps the first
+    # timed leg read 0.499 ms per step on a box whose steady state is 0.456; a freshly leased box was still falling
+    # after 150 steps), and torch's caching allocator takes its 134 MB blocks from the driver during the first steps.
+    precond = precondition(layer, u, gy, dist_on, flat)
     dt = timed(layer, u, gy, a.steps, a.warmup, dist_on, flat)
     headline_diag = dict(LAST_DIAG)
     layer.checkpoint_policy = "auto"
@@ -532,8 +559,9 @@ def main():
                        "global_batch": B * world, "parallelism": f"dp{world}",
                        "grad_allreduce_bytes": (flat.nbytes() if flat is not None else 0),
                        "rccl_world_size": rccl_ws},
-            "preconditioning": f"{PRECONDITION_STEPS} untimed steps of this workload during set-up, before the {a.warmup} warm-up "
-                               "steps (device clocks and allocator pools in their steady state)",
+            "preconditioning": dict(precond, note=f"untimed batches of {PRECONDITION_BATCH} steps of this workload during set-up, before "
+                                                  f"the {a.warmup} warm-up steps, until the batch time has stopped falling (device "
+                                                  "clocks and allocator pools in their steady state)"),
             "checkpoint_policy": "lagged (the backward's checkpoint plan comes from the previous step's coefficient maxima: no "
                                  "host wait inside the step; both plans are 'no checkpoints' on this workload)",
             "eager_auto_policy": {"ms_per_step": auto_ms, "value": B * world / (auto_ms * 1e-3) / 1e6, "unit": "Msamples/s",
